@@ -1,0 +1,107 @@
+"""Oracle: tile enumeration and stitching (integer / copy work, numpy).
+
+Follows ``data/tiling_manager.py`` and ``data/tile_stitcher.py``.  Test
+infrastructure only (see ``oracle/__init__.py``).
+"""
+import math
+
+import numpy as np
+
+TRIM, PAD, SHIFT = 0, 1, 2  # tiling_manager.py:6-12
+
+
+class TilePlan:
+    """Restatement of ``TileIndexManager`` (tiling_manager.py:14-154)."""
+
+    def __init__(self, data_shape, grid_shape, patch_shape, mode=SHIFT):
+        self.data_shape = tuple(int(v) for v in data_shape)
+        self.grid_shape = tuple(int(v) for v in grid_shape)
+        self.patch_shape = tuple(int(v) for v in patch_shape)
+        self.mode = mode
+        assert len(self.data_shape) == len(self.grid_shape) == len(self.patch_shape)
+        for d, (p, g) in enumerate(zip(self.patch_shape, self.grid_shape)):  # :21-29
+            if p - g < 0 or (p - g) % 2:
+                raise ValueError(f"bad patch/grid in dim {d}")
+
+    def patch_offset(self):  # :31-32
+        return tuple((p - g) // 2 for p, g in zip(self.patch_shape, self.grid_shape))
+
+    def dim_count(self, dim):  # :34-50
+        D, g, p = self.data_shape[dim], self.grid_shape[dim], self.patch_shape[dim]
+        if g == 1 and p == 1:
+            return D
+        if self.mode == PAD:
+            return int(math.ceil(D / g))
+        if self.mode == SHIFT:
+            return int(math.ceil((D - (p - g)) / g))
+        return int(math.floor((D - (p - g)) / g))
+
+    def grid_count(self, dim):  # :58-68 (tiles per unit index of `dim`)
+        n = 1
+        for d in range(dim + 1, len(self.data_shape)):
+            n *= self.dim_count(d)
+        return n
+
+    def total(self):  # :52-56
+        return self.grid_count(0) * self.dim_count(0)
+
+    def grid_start(self, dim, k):  # :121-143
+        D, g, p = self.data_shape[dim], self.grid_shape[dim], self.patch_shape[dim]
+        ex = (p - g) // 2
+        if g == 1 and p == 1:
+            return k
+        if self.mode == PAD:
+            return k * g
+        if self.mode == TRIM:
+            return k * g + ex
+        if k < self.dim_count(dim) - 1:
+            return k * g + ex
+        return D - g - ex
+
+    def location(self, idx):  # :145-154
+        loc = []
+        for d in range(len(self.data_shape)):
+            gc = self.grid_count(d)
+            loc.append(self.grid_start(d, idx // gc))
+            idx %= gc
+        return tuple(loc)
+
+    def patch_location(self, idx):  # :106-112
+        return tuple(l - o for l, o in zip(self.location(idx), self.patch_offset()))
+
+    def valid_region(self, idx):
+        """tile_stitcher.py:26-56: (vgs, vge, rs, re) for one tile."""
+        gs = np.array(self.location(idx), dtype=int)
+        ge = gs + np.array(self.grid_shape)
+        ps = gs - np.array(self.patch_offset())
+        pe = ps + np.array(self.patch_shape)
+        vgs, vge = gs.copy(), ge.copy()
+        if self.mode == SHIFT:
+            for d in range(len(gs)):
+                if ps[d] == 0:
+                    vgs[d] = 0
+                if pe[d] == self.data_shape[d]:
+                    vge[d] = self.data_shape[d]
+        rs = vgs - ps
+        re = rs + (vge - vgs)
+        return vgs, vge, rs, re
+
+
+def stitch(predictions, plan):
+    """tile_stitcher.py:10-81 for 3-D data (N,H,W): predictions (T,C,ph,pw) -> (N,H,W,C)."""
+    out = np.zeros(list(plan.data_shape) + [predictions.shape[1]], dtype=predictions.dtype)
+    for i in range(predictions.shape[0]):
+        vgs, vge, rs, re = plan.valid_region(i)
+        for c in range(predictions.shape[1]):
+            out[vgs[0]:vge[0], vgs[1]:vge[1], vgs[2]:vge[2], c] = \
+                predictions[i][c, rs[1]:re[1], rs[2]:re[2]]
+    return out
+
+
+def extract_patch(frames, plan, idx):
+    """What SplitDatasetTiledPred yields for tile ``idx`` before normalisation:
+    the (C, p, p) crop at ``patch_location`` (split_dataset_tiledpred.py:30-32 with
+    split_dataset.py patch extraction).  ``frames``: (N,H,W,C)."""
+    n, y, x = plan.patch_location(idx)
+    p = plan.patch_shape
+    return np.moveaxis(frames[n, y:y + p[1], x:x + p[2], :], -1, 0)
