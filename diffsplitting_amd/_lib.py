@@ -1,0 +1,87 @@
+"""ctypes binding of libdsx.so (C ABI: include/dsx.h).
+
+The HIP library is the product path; there is no CPU fallback.  Importing this
+module without a built ``libdsx.so`` raises, and every compute entry point
+raises ``DsxError`` when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsx.so")
+
+
+class DsxError(RuntimeError):
+    pass
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [("flavour", C.c_int32), ("in_channel", C.c_int32), ("out_channel", C.c_int32),
+                ("inner_channel", C.c_int32), ("norm_groups", C.c_int32), ("n_mults", C.c_int32),
+                ("channel_mults", C.c_int32 * 8), ("n_attn_res", C.c_int32), ("attn_res", C.c_int32 * 8),
+                ("res_blocks", C.c_int32), ("image_size", C.c_int32), ("with_time_emb", C.c_int32)]
+
+
+class StepTable(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("predict_eps", C.c_int32), ("clip", C.c_int32),
+                ("tcond", C.POINTER(C.c_float)), ("a", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float)),
+                ("c1", C.POINTER(C.c_float)), ("c2", C.POINTER(C.c_float)), ("sigma", C.POINTER(C.c_float))]
+
+
+FLAVOUR_SR3, FLAVOUR_DDPM = 0, 1
+DTYPE_F32, DTYPE_BF16 = 0, 1
+TILING_TRIM, TILING_PAD, TILING_SHIFT = 0, 1, 2
+
+_vp, _i, _i64, _u64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+_pi64, _pi32, _pf = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); exactly the declarations of include/dsx.h
+SIGNATURES = {
+    "dsx_last_error": (C.c_char_p, []),
+    "dsx_abi_version": (_i, []),
+    "dsx_device_count": (_i, []),
+    "dsx_model_create": (_i, [C.POINTER(UnetCfg), C.POINTER(_vp)]),
+    "dsx_model_destroy": (None, [_vp]),
+    "dsx_model_num_params": (_i, [_vp]),
+    "dsx_model_param_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), _pi64]),
+    "dsx_model_set_param": (_i, [_vp, _i, _vp, _i64]),
+    "dsx_model_set_posenc_freq": (_i, [_vp, _vp, _i]),
+    "dsx_model_finalize": (_i, [_vp, _i]),
+    "dsx_model_flops": (C.c_double, [_vp, _i, _i]),
+    "dsx_exec_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "dsx_exec_destroy": (None, [_vp]),
+    "dsx_exec_workspace_bytes": (C.c_size_t, [_vp]),
+    "dsx_exec_num_launches": (_i, [_vp]),
+    "dsx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "dsx_time_predictor_set_mask": (_i, [_vp, _vp, _vp]),
+    "dsx_time_predictor_forward": (_i, [_vp, _vp, _vp, _vp]),
+    "dsx_sample_loop": (_i, [_vp, C.POINTER(StepTable), _vp, _vp, _vp, _u64, _pi32, _i, _vp, _i, _vp]),
+    "dsx_randn": (_i, [_vp, _i64, _u64, _u64, _vp]),
+    "dsx_tile_plan": (_i64, [_pi64, _pi64, _pi64, _i, _pi64, _pi64, _i64]),
+    "dsx_tile_regions": (_i, [_pi64, _pi64, _pi64, _i, _pi32, _i64]),
+    "dsx_tiles_gather": (_i, [_vp, _pi64, _pi64, _pi64, _pi64, _i64, _vp, _vp]),
+    "dsx_stitch": (_i, [_vp, _i64, _i, _i, _i, _pi32, _vp, _pi64, _vp]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the sampling path.")
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc):
+    """Raise DsxError with the library's message on a negative status."""
+    if rc is not None and rc < 0:
+        raise DsxError(f"libdsx status {rc}: {lib.dsx_last_error().decode(errors='replace')}")
+    return rc
+
+
+def require_gpu():
+    if lib.dsx_device_count() < 1:
+        raise DsxError("no HIP device visible: the sampling path runs on MI355X only (no CPU fallback)")

@@ -1,0 +1,153 @@
+// dsx_kernels.h — launch interface between the host runtime (dsx_runtime.cpp)
+// and the gfx950 kernels (dsx_kernels.hip).  Internal; the public ABI is
+// include/dsx.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsx {
+
+// ---------------------------------------------------------------------------
+// Fused conv:  out = conv_{KSxKS, stride S}( act( gn(x) ) ) + bias + film + resid
+//   x is the channel-concatenation of up to two NHWC fp32 tensors (skip
+//   connections are never materialised), optionally nearest-upsampled x2.
+//   Implicit GEMM on MFMA: M = output pixels, N = Cout, K = taps x Cin.
+// ---------------------------------------------------------------------------
+struct ConvArgs {
+  const float* src0;
+  const float* src1;
+  int C0, C1;             // channels per source (C1 == 0: single source)
+  int B, Hs, Ws;          // source spatial size (before the optional upsample)
+  int up;                 // 1: nearest x2 upsample fused into the patch load
+  int Ho, Wo;             // output spatial size
+  const float* gn_scale;  // [B][C0+C1] or nullptr:  v = x*scale + shift
+  const float* gn_shift;
+  int swish;              // v = v*sigmoid(v) after the affine
+  int scalar_stage;       // channel counts not multiples of 4: per-element loads
+  const void* wpack;      // MFMA-fragment-ordered weights (fp32 or bf16)
+  const float* bias;      // [Cout] or nullptr
+  const float* film;      // film[b*film_bs + n] or nullptr (FiLM / time-embedding add)
+  int film_bs;
+  const float* resid;     // [B][Ho][Wo][resid_ld] or nullptr
+  int resid_ld;
+  float* out;             // [B][Ho][Wo][out_ld]
+  int out_ld;
+  int Cout;
+  int nblocks;            // ceil(Cout/32)
+  int kchunks;            // ceil((C0+C1)/KC)
+  int tw_log2, th_log2, tb_log2;  // output tile = TB images x TH x TW pixels
+  int tiles_x, tiles_y, m_tiles;
+};
+
+// tile configurations compiled for the MFMA conv kernel
+enum ConvTile { TILE_256x128 = 0, TILE_256x64, TILE_128x64, TILE_64x64, TILE_COUNT };
+struct ConvTileInfo { int BM, BN; };
+ConvTileInfo conv_tile_info(int tile);
+// LDS bytes needed by a launch; 0 if the geometry is not supported by `tile`
+size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a);
+hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& a, hipStream_t st);
+// one-time function attributes (dynamic LDS limit); call outside any stream capture
+hipError_t conv_init();
+
+// Plain direct convolution (one thread per output element), any odd KS, stride 1,
+// weights [Cout][KS][KS][Cin] fp32.  Used for the 7x7 ForegroundMask conv and as
+// an on-device cross-check of the MFMA path (DSX_CONV_IMPL=naive).
+struct NaiveConvArgs {
+  ConvArgs c;
+  const float* w;  // [Cout][KS][KS][C]
+  int ks, stride;
+  int sigmoid_out;
+};
+hipError_t launch_conv_naive(const NaiveConvArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// GroupNorm statistics
+// ---------------------------------------------------------------------------
+// per-(image, pixel-chunk, channel) partial {sum, sumsq} in double:
+//   part[((b*nchunk + ch)*C + c)*2 + {0,1}]
+hipError_t launch_chan_stats(const float* x, int B, int HW, int C, int nchunk, double* part,
+                             hipStream_t st);
+// GroupNorm of the concatenation of (t0, t1) -> scale/shift[b][C0+C1]
+struct GnFinArgs {
+  const double* part0; int C0, nchunk0;
+  const double* part1; int C1, nchunk1;
+  int B, groups;
+  double count;          // elements per channel (H*W)
+  const float* gamma;    // [C0+C1]
+  const float* beta;
+  float eps;
+  float* scale;          // [B][C0+C1]
+  float* shift;
+};
+hipError_t launch_gn_finalize(const GnFinArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// time embedding + all FiLM vectors of one forward in one launch
+// ---------------------------------------------------------------------------
+struct TembArgs {
+  int flavour;            // 0 sr3 (PositionalEncoding), 1 ddpm (TimeEmbedding)
+  int B;                  // rows to produce
+  int n_time;             // B or 1 (broadcast)
+  const float* time;      // direct time values, or nullptr -> table[*step_ctr]
+  const float* table;     // per-step tcond table (device)
+  const int* step_ctr;
+  int inner;              // C0
+  const float* freq;      // [inner/2]
+  const float* w1; const float* b1;   // [4*inner][inner], [4*inner]
+  const float* w2; const float* b2;   // [inner][4*inner], [inner]
+  const float* wf; const float* bf;   // all FiLM linears stacked: [F][inner], [F]
+  int F;
+  float* film;            // [B][F]
+};
+hipError_t launch_temb(const TembArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// attention (single head, d = C):  S = QK^T/sqrt(C); P = softmax(S); O = PV
+// ---------------------------------------------------------------------------
+struct BgemmArgs {
+  const float* A; int lda; long long sA;   // A[bt][m][k]
+  const float* Bm; int ldb; long long sB;  // b_kmajor=0: B[bt][n][k]; 1: B[bt][k][n]
+  int b_kmajor;
+  float* Cm; int ldc; long long sC;
+  int M, N, K, batch;
+  float div;                               // C = acc / div
+};
+hipError_t launch_bgemm(const BgemmArgs& a, hipStream_t st);
+hipError_t launch_softmax_rows(float* S, long long rows, int L, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// layout, sampler update, RNG, tiling
+// ---------------------------------------------------------------------------
+// dst[b][hw][c] = src[(b*ctot + coff + c)*HW + hw]   (channel slice of an NCHW tensor -> NHWC)
+hipError_t launch_nchw_slice_to_nhwc(const float* src, float* dst, int B, int C, int ctot, int coff, int HW,
+                                     hipStream_t st);
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, hipStream_t st);
+
+struct UpdateArgs {
+  float* x;               // state, NHWC [B][H][W][C]
+  const float* net;       // UNet output, NHWC
+  const float* noise;     // nullptr -> Philox; else [n_steps][B][C][H][W] (NCHW, reference draw order)
+  unsigned long long seed;
+  const float* tab;       // device table [6][n_steps]: tcond,a,b,c1,c2,sigma
+  int n_steps;
+  const int* step_ctr;
+  int predict_eps, clip;
+  int B, C, H, W;
+};
+hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
+hipError_t launch_advance(int* step_ctr, hipStream_t st);
+hipError_t launch_randn(float* out, long long n, unsigned long long seed, unsigned long long subseq,
+                        hipStream_t st);
+
+hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw,
+                               const int* starts /*dev [count][3]*/, long long count, float* tiles,
+                               hipStream_t st);
+hipError_t launch_stitch(const float* tiles, long long count, int C, int ph, int pw,
+                         const int* regions /*dev [count][8]*/, float* canvas, int H, int W,
+                         hipStream_t st);
+
+// relu(u) * sigmoid-mask reduction of the TimePredictor head
+hipError_t launch_masked_mean(const float* u, const float* mask, int B, long long n, float* out,
+                              hipStream_t st);
+
+}  // namespace dsx

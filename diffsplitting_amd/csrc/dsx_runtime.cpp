@@ -1,0 +1,1139 @@
+// dsx_runtime.cpp — host side of libdsx.so: UNet topology + parameter table in
+// the reference's state_dict order, weight repacking into MFMA fragment order,
+// the per-(B,H,W) launch plan, the graph-captured sampling loop and the tile
+// planner.  C ABI in include/dsx.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/dsx.h"
+#include "dsx_kernels.h"
+
+using namespace dsx;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return fail(DSX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),    \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+extern "C" const char* dsx_last_error(void) { return g_err.c_str(); }
+extern "C" int dsx_abi_version(void) { return DSX_ABI_VERSION; }
+extern "C" int dsx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+// ------------------------------------------------------------------ model
+namespace {
+
+struct Param {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::vector<float> host;
+  bool set = false;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct ConvW {
+  int pw = -1, pb = -1;  // param indices (weight, bias)
+  int cin = 0, cout = 0, ks = 1;
+  int kchunks = 0, nblocks = 0;
+  void* pack = nullptr;     // device, fragment order
+  float* bias = nullptr;    // device
+  float* naive = nullptr;   // device [Cout][ks][ks][Cin] (debug / 7x7 only)
+};
+struct GnW {
+  int pg = -1, pb = -1;
+  int C = 0;
+  float* gamma = nullptr;
+  float* beta = nullptr;
+};
+struct LinW {
+  int pw = -1, pb = -1;
+  int in = 0, out = 0;
+};
+
+struct Module {
+  int kind;  // 0 conv_in, 1 res, 2 down, 3 up, 4 final
+  int section;  // 0 downs, 1 mid, 2 ups, 3 final
+  int cin = 0, cout = 0, skip = 0;
+  bool attn = false;
+  ConvW conv;             // conv_in / down / up / final conv
+  GnW gn1, gn2, gna;      // res: block1/2 norms, attention norm; final: gn1
+  ConvW conv1, conv2, res, qkv, out;
+  bool has_res = false;
+  LinW film;
+  int film_off = -1;
+};
+
+}  // namespace
+
+struct dsx_model {
+  dsx_unet_cfg cfg;
+  std::vector<Param> params;
+  std::vector<Module> mods;
+  // time embedding
+  int p_invfreq = -1;
+  LinW t1, t2;
+  std::vector<float> freq;  // inner/2
+  bool freq_set = false;
+  int F = 0;                // stacked FiLM outputs
+  // device
+  bool finalized = false;
+  int dtype = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  float *d_freq = nullptr, *d_w1 = nullptr, *d_b1 = nullptr, *d_w2 = nullptr, *d_b2 = nullptr;
+  float *d_wf = nullptr, *d_bf = nullptr;
+  bool want_naive = false;
+};
+
+static int add_param(dsx_model* m, const std::string& name, std::initializer_list<int64_t> shape) {
+  Param p;
+  p.name = name;
+  p.shape.assign(shape.begin(), shape.end());
+  m->params.push_back(std::move(p));
+  return (int)m->params.size() - 1;
+}
+static ConvW add_conv(dsx_model* m, const std::string& pfx, int cin, int cout, int ks, bool bias) {
+  ConvW c;
+  c.cin = cin; c.cout = cout; c.ks = ks;
+  c.pw = add_param(m, pfx + ".weight", {cout, cin, ks, ks});
+  if (bias) c.pb = add_param(m, pfx + ".bias", {cout});
+  return c;
+}
+static GnW add_gn(dsx_model* m, const std::string& pfx, int C) {
+  GnW g;
+  g.C = C;
+  g.pg = add_param(m, pfx + ".weight", {C});
+  g.pb = add_param(m, pfx + ".bias", {C});
+  return g;
+}
+static LinW add_lin(dsx_model* m, const std::string& pfx, int in, int out) {
+  LinW l;
+  l.in = in; l.out = out;
+  l.pw = add_param(m, pfx + ".weight", {out, in});
+  l.pb = add_param(m, pfx + ".bias", {out});
+  return l;
+}
+
+// ResnetBlocWithAttn in state_dict order (sr3 unet.py:94-158, ddpm unet.py:78-146)
+static void add_res(dsx_model* m, const std::string& pfx, Module& md) {
+  const dsx_unet_cfg& c = m->cfg;
+  const std::string rb = pfx + ".res_block";
+  if (c.with_time_emb) {
+    md.film = add_lin(m, c.flavour == DSX_FLAVOUR_SR3 ? rb + ".noise_func.noise_func.0" : rb + ".mlp.1",
+                      c.inner_channel, md.cout);
+    md.film_off = m->F;
+    m->F += md.cout;
+  }
+  md.gn1 = add_gn(m, rb + ".block1.block.0", md.cin);
+  md.conv1 = add_conv(m, rb + ".block1.block.3", md.cin, md.cout, 3, true);
+  md.gn2 = add_gn(m, rb + ".block2.block.0", md.cout);
+  md.conv2 = add_conv(m, rb + ".block2.block.3", md.cout, md.cout, 3, true);
+  md.has_res = md.cin != md.cout;
+  if (md.has_res) md.res = add_conv(m, rb + ".res_conv", md.cin, md.cout, 1, true);
+  if (md.attn) {
+    md.gna = add_gn(m, pfx + ".attn.norm", md.cout);
+    md.qkv = add_conv(m, pfx + ".attn.qkv", md.cout, 3 * md.cout, 1, false);
+    md.out = add_conv(m, pfx + ".attn.out", md.cout, md.cout, 1, true);
+  }
+}
+
+extern "C" int dsx_model_create(const dsx_unet_cfg* cfg, dsx_model** out) {
+  if (!cfg || !out) return fail(DSX_ERR_INVALID, "null argument");
+  if (cfg->n_mults < 1 || cfg->n_mults > 8 || cfg->n_attn_res < 0 || cfg->n_attn_res > 8)
+    return fail(DSX_ERR_INVALID, "bad n_mults/n_attn_res");
+  if (cfg->inner_channel < 4 || cfg->inner_channel % 4 || cfg->norm_groups < 1)
+    return fail(DSX_ERR_INVALID, "inner_channel must be a positive multiple of 4");
+  for (int i = 0; i < cfg->n_mults; ++i)
+    if ((cfg->inner_channel * cfg->channel_mults[i]) % cfg->norm_groups)
+      return fail(DSX_ERR_INVALID, "norm_groups must divide every level's channel count");
+  dsx_model* m = new dsx_model();
+  m->cfg = *cfg;
+  const int inner = cfg->inner_channel;
+  auto in_attn = [&](int res) {
+    for (int i = 0; i < cfg->n_attn_res; ++i)
+      if (cfg->attn_res[i] == res) return true;
+    return false;
+  };
+  // time embedding MLP (sr3 unet.py:177-187 / ddpm unet.py:163-173)
+  if (cfg->with_time_emb) {
+    if (cfg->flavour == DSX_FLAVOUR_SR3) {
+      m->t1 = add_lin(m, "noise_level_mlp.1", inner, 4 * inner);
+      m->t2 = add_lin(m, "noise_level_mlp.3", 4 * inner, inner);
+    } else {
+      m->p_invfreq = add_param(m, "time_mlp.0.inv_freq", {inner / 2});
+      m->t1 = add_lin(m, "time_mlp.1", inner, 4 * inner);
+      m->t2 = add_lin(m, "time_mlp.3", 4 * inner, inner);
+    }
+  }
+  // downs
+  int pre = inner, now_res = cfg->image_size, idx = 0;
+  std::vector<int> feat{pre};
+  {
+    Module md{};
+    md.kind = 0; md.section = 0; md.cin = cfg->in_channel; md.cout = inner;
+    md.conv = add_conv(m, "downs.0", cfg->in_channel, inner, 3, true);
+    m->mods.push_back(md);
+    idx = 1;
+  }
+  for (int ind = 0; ind < cfg->n_mults; ++ind) {
+    const bool last = ind == cfg->n_mults - 1;
+    const bool use_attn = in_attn(now_res);
+    const int ch = inner * cfg->channel_mults[ind];
+    for (int r = 0; r < cfg->res_blocks; ++r) {
+      Module md{};
+      md.kind = 1; md.section = 0; md.cin = pre; md.cout = ch; md.attn = use_attn;
+      add_res(m, "downs." + std::to_string(idx++), md);
+      m->mods.push_back(md);
+      feat.push_back(ch);
+      pre = ch;
+    }
+    if (!last) {
+      Module md{};
+      md.kind = 2; md.section = 0; md.cin = pre; md.cout = pre;
+      md.conv = add_conv(m, "downs." + std::to_string(idx++) + ".conv", pre, pre, 3, true);
+      m->mods.push_back(md);
+      feat.push_back(pre);
+      now_res /= 2;
+    }
+  }
+  for (int k = 0; k < 2; ++k) {
+    Module md{};
+    md.kind = 1; md.section = 1; md.cin = pre; md.cout = pre; md.attn = (k == 0);
+    add_res(m, "mid." + std::to_string(k), md);
+    m->mods.push_back(md);
+  }
+  idx = 0;
+  for (int ind = cfg->n_mults - 1; ind >= 0; --ind) {
+    const bool last = ind < 1;
+    const bool use_attn = in_attn(now_res);
+    const int ch = inner * cfg->channel_mults[ind];
+    for (int r = 0; r < cfg->res_blocks + 1; ++r) {
+      Module md{};
+      md.kind = 1; md.section = 2; md.skip = feat.back(); feat.pop_back();
+      md.cin = pre + md.skip; md.cout = ch; md.attn = use_attn;
+      if (md.cin % cfg->norm_groups) {
+        delete m;
+        return fail(DSX_ERR_INVALID, "norm_groups must divide concatenated channel counts");
+      }
+      add_res(m, "ups." + std::to_string(idx++), md);
+      m->mods.push_back(md);
+      pre = ch;
+    }
+    if (!last) {
+      Module md{};
+      md.kind = 3; md.section = 2; md.cin = pre; md.cout = pre;
+      md.conv = add_conv(m, "ups." + std::to_string(idx++) + ".conv", pre, pre, 3, true);
+      m->mods.push_back(md);
+      now_res *= 2;
+    }
+  }
+  {
+    Module md{};
+    md.kind = 4; md.section = 3; md.cin = pre;
+    md.cout = cfg->out_channel > 0 ? cfg->out_channel : cfg->in_channel;
+    md.gn1 = add_gn(m, "final_conv.block.0", pre);
+    md.conv = add_conv(m, "final_conv.block.3", pre, md.cout, 3, true);
+    m->mods.push_back(md);
+  }
+  const char* env = getenv("DSX_CONV_IMPL");
+  m->want_naive = env && !strcmp(env, "naive");
+  *out = m;
+  return DSX_OK;
+}
+
+extern "C" void dsx_model_destroy(dsx_model* m) {
+  if (!m) return;
+  if (m->arena) (void)hipFree(m->arena);
+  delete m;
+}
+extern "C" int dsx_model_num_params(const dsx_model* m) { return m ? (int)m->params.size() : 0; }
+extern "C" int dsx_model_param_info(const dsx_model* m, int i, char* name, int cap, int* ndim,
+                                    int64_t shape[4]) {
+  if (!m || i < 0 || i >= (int)m->params.size()) return fail(DSX_ERR_INVALID, "bad param index");
+  const Param& p = m->params[i];
+  if (name && cap > 0) snprintf(name, cap, "%s", p.name.c_str());
+  if (ndim) *ndim = (int)p.shape.size();
+  if (shape)
+    for (size_t k = 0; k < 4; ++k) shape[k] = k < p.shape.size() ? p.shape[k] : 1;
+  return DSX_OK;
+}
+extern "C" int dsx_model_set_param(dsx_model* m, int i, const float* data, int64_t numel) {
+  if (!m || !data || i < 0 || i >= (int)m->params.size()) return fail(DSX_ERR_INVALID, "bad argument");
+  Param& p = m->params[i];
+  if (numel != p.numel())
+    return fail(DSX_ERR_INVALID, "param %s: got %lld elements, expected %lld", p.name.c_str(),
+                (long long)numel, (long long)p.numel());
+  p.host.assign(data, data + numel);
+  p.set = true;
+  m->finalized = false;
+  return DSX_OK;
+}
+extern "C" int dsx_model_set_posenc_freq(dsx_model* m, const float* f, int count) {
+  if (!m || !f || count != m->cfg.inner_channel / 2) return fail(DSX_ERR_INVALID, "bad freq table");
+  m->freq.assign(f, f + count);
+  m->freq_set = true;
+  m->finalized = false;
+  return DSX_OK;
+}
+
+// fp32 -> bf16 round-to-nearest-even (finite inputs)
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// OIHW fp32 -> [nblk][kchunk][tap][half][lane][16 B] (see dsx_conv.hip header)
+static void pack_conv(const float* w, int cout, int cin, int ks, int dtype, std::vector<char>& dst,
+                      int& kchunks, int& nblocks) {
+  const int KC = dtype == 1 ? 32 : 16, EPL = dtype == 1 ? 8 : 4, taps = ks * ks;
+  kchunks = (cin + KC - 1) / KC;
+  nblocks = (cout + 31) / 32;
+  dst.assign((size_t)nblocks * kchunks * taps * 2 * 64 * 16, 0);
+  for (int nb = 0; nb < nblocks; ++nb)
+    for (int kc = 0; kc < kchunks; ++kc)
+      for (int tap = 0; tap < taps; ++tap)
+        for (int fs = 0; fs < 2; ++fs)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31, h = lane >> 5, n = nb * 32 + i;
+            char* p = dst.data() + ((((size_t)(nb * kchunks + kc) * taps + tap) * 2 + fs) * 64 + lane) * 16;
+            for (int j = 0; j < EPL; ++j) {
+              const int c = kc * KC + (KC / 2) * fs + EPL * h + j;
+              float v = 0.f;
+              if (n < cout && c < cin) v = w[((size_t)n * cin + c) * taps + tap];
+              if (dtype == 1) { uint16_t b = f2bf(v); memcpy(p + 2 * j, &b, 2); }
+              else memcpy(p + 4 * j, &v, 4);
+            }
+          }
+}
+
+extern "C" int dsx_model_finalize(dsx_model* m, int dtype) {
+  if (!m) return fail(DSX_ERR_INVALID, "null model");
+  if (dtype != DSX_DTYPE_F32 && dtype != DSX_DTYPE_BF16) return fail(DSX_ERR_INVALID, "bad dtype");
+  for (int i = 0; i < (int)m->params.size(); ++i) {
+    if (m->params[i].set || i == m->p_invfreq) continue;  // inv_freq is derived below if absent
+    return fail(DSX_ERR_MISSING, "parameter %s was never set", m->params[i].name.c_str());
+  }
+  const int inner = m->cfg.inner_channel;
+  if (m->cfg.with_time_emb) {
+    if (m->cfg.flavour == DSX_FLAVOUR_DDPM) {
+      Param& p = m->params[m->p_invfreq];
+      if (p.set) m->freq = p.host;
+      else {  // ddpm unet.py:22-26
+        m->freq.resize(inner / 2);
+        for (int k = 0; k < inner / 2; ++k) m->freq[k] = expf((float)(2 * k) * (float)(-log(10000.0) / inner));
+      }
+    } else if (!m->freq_set) {  // sr3 unet.py:24-28
+      m->freq.resize(inner / 2);
+      for (int k = 0; k < inner / 2; ++k)
+        m->freq[k] = expf((float)(-log(1e4)) * ((float)k / (float)(inner / 2)));
+    }
+  }
+  // ---- build one host image of everything that goes to the device
+  std::vector<char> img;
+  auto reserve = [&](size_t bytes) {
+    size_t off = (img.size() + 255) & ~(size_t)255;
+    img.resize(off + bytes);
+    return off;
+  };
+  struct Fix { void** dst; size_t off; };
+  std::vector<Fix> fix;
+  auto put_f32 = [&](const std::vector<float>& v, float** dst) {
+    size_t off = reserve(v.size() * 4);
+    memcpy(img.data() + off, v.data(), v.size() * 4);
+    fix.push_back({(void**)dst, off});
+  };
+  auto put_conv = [&](ConvW& c) {
+    if (c.pw < 0) return;
+    std::vector<char> pk;
+    pack_conv(m->params[c.pw].host.data(), c.cout, c.cin, c.ks, dtype, pk, c.kchunks, c.nblocks);
+    size_t off = reserve(pk.size());
+    memcpy(img.data() + off, pk.data(), pk.size());
+    fix.push_back({&c.pack, off});
+    if (c.pb >= 0) put_f32(m->params[c.pb].host, &c.bias);
+    if (m->want_naive) {
+      std::vector<float> nv((size_t)c.cout * c.ks * c.ks * c.cin);
+      const float* w = m->params[c.pw].host.data();
+      for (int n = 0; n < c.cout; ++n)
+        for (int ci = 0; ci < c.cin; ++ci)
+          for (int t = 0; t < c.ks * c.ks; ++t)
+            nv[((size_t)n * c.ks * c.ks + t) * c.cin + ci] = w[((size_t)n * c.cin + ci) * c.ks * c.ks + t];
+      put_f32(nv, &c.naive);
+    }
+  };
+  auto put_gn = [&](GnW& g) {
+    if (g.pg < 0) return;
+    put_f32(m->params[g.pg].host, &g.gamma);
+    put_f32(m->params[g.pb].host, &g.beta);
+  };
+  std::vector<float> wf((size_t)m->F * inner), bf(m->F);
+  for (auto& md : m->mods) {
+    put_conv(md.conv);
+    put_gn(md.gn1); put_gn(md.gn2); put_gn(md.gna);
+    put_conv(md.conv1); put_conv(md.conv2);
+    if (md.has_res) put_conv(md.res);
+    if (md.attn) { put_conv(md.qkv); put_conv(md.out); }
+    if (md.film_off >= 0) {
+      memcpy(wf.data() + (size_t)md.film_off * inner, m->params[md.film.pw].host.data(),
+             (size_t)md.cout * inner * 4);
+      memcpy(bf.data() + md.film_off, m->params[md.film.pb].host.data(), (size_t)md.cout * 4);
+    }
+  }
+  if (m->cfg.with_time_emb) {
+    put_f32(m->freq, &m->d_freq);
+    put_f32(m->params[m->t1.pw].host, &m->d_w1);
+    put_f32(m->params[m->t1.pb].host, &m->d_b1);
+    put_f32(m->params[m->t2.pw].host, &m->d_w2);
+    put_f32(m->params[m->t2.pb].host, &m->d_b2);
+    put_f32(wf, &m->d_wf);
+    put_f32(bf, &m->d_bf);
+  }
+  if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }
+  HIP_TRY(hipMalloc((void**)&m->arena, img.size()));
+  HIP_TRY(hipMemcpy(m->arena, img.data(), img.size(), hipMemcpyHostToDevice));
+  m->arena_bytes = img.size();
+  for (auto& f : fix) *f.dst = m->arena + f.off;
+  m->dtype = dtype;
+  m->finalized = true;
+  return DSX_OK;
+}
+
+extern "C" double dsx_model_flops(const dsx_model* m, int H, int W) {
+  if (!m) return 0;
+  double fl = 0;
+  int h = H, w = W;
+  const int inner = m->cfg.inner_channel;
+  auto conv = [&](const ConvW& c, int hh, int ww) {
+    if (c.pw >= 0) fl += 2.0 * hh * ww * (double)c.cout * c.cin * c.ks * c.ks;
+  };
+  if (m->cfg.with_time_emb) fl += 2.0 * (inner * 4.0 * inner) * 2;
+  for (auto& md : m->mods) {
+    if (md.kind == 0) conv(md.conv, h, w);
+    else if (md.kind == 2) { h /= 2; w /= 2; conv(md.conv, h, w); }
+    else if (md.kind == 3) { h *= 2; w *= 2; conv(md.conv, h, w); }
+    else if (md.kind == 4) conv(md.conv, h, w);
+    else {
+      conv(md.conv1, h, w); conv(md.conv2, h, w);
+      if (md.has_res) conv(md.res, h, w);
+      if (md.film_off >= 0) fl += 2.0 * inner * md.cout;
+      if (md.attn) {
+        conv(md.qkv, h, w); conv(md.out, h, w);
+        const double L = (double)h * w;
+        fl += 2.0 * 2.0 * L * L * md.cout;
+      }
+    }
+  }
+  return fl;
+}
+
+// ------------------------------------------------------------------ executor
+namespace {
+
+struct Tensor {
+  float* p = nullptr;
+  int C = 0, H = 0, W = 0;
+  int id = -1;             // index into dsx_exec::stats (copies of a Tensor share it)
+};
+struct StatInfo {          // GroupNorm partial sums of one tensor, produced at most once
+  double* part = nullptr;
+  int nchunk = 0;
+  bool planned = false;
+};
+
+struct LoopState {   // device-resident, read by k_temb / k_update
+  int step;
+  int pad;
+};
+
+}  // namespace
+
+struct dsx_exec {
+  dsx_model* m = nullptr;
+  int B = 0, H = 0, W = 0, cond_c = 0, x_c = 0;
+  char* ws = nullptr;
+  size_t ws_bytes = 0, ws_used = 0;
+  bool sizing = true;
+  std::vector<std::function<hipError_t(hipStream_t)>> ops;  // the UNet forward
+  std::vector<StatInfo> stats;
+  // fixed buffers
+  Tensor in_cond, in_x, out;   // NHWC
+  float* film = nullptr;       // [B][F]
+  float* time_buf = nullptr;   // [B] direct time values
+  int* step_ctr = nullptr;
+  float* table = nullptr;      // [6][cap]
+  int table_cap = 0;
+  std::vector<float> table_host;
+  bool temb_from_table = false;
+  const float* upd_noise = nullptr;
+  unsigned long long upd_seed = 0;
+  dsx_step_table cur_tab{};
+  // graph
+  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph = nullptr;
+  std::vector<float> graph_sig;
+  // time predictor head
+  float* tp_w = nullptr; float* tp_b = nullptr; float* tp_mask = nullptr;
+  int launches = 0;
+};
+
+static char* ws_alloc(dsx_exec* ex, size_t bytes) {
+  size_t off = (ex->ws_used + 255) & ~(size_t)255;
+  ex->ws_used = off + bytes;
+  if (ex->sizing) return nullptr;
+  return ex->ws + off;
+}
+static Tensor new_tensor(dsx_exec* ex, int C, int H, int W) {
+  Tensor t;
+  t.C = C; t.H = H; t.W = W;
+  t.p = (float*)ws_alloc(ex, (size_t)ex->B * H * W * C * sizeof(float));
+  t.id = (int)ex->stats.size();
+  ex->stats.push_back(StatInfo());
+  return t;
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
+static int pow2_divisor(int v, int cap) {  // largest power of two dividing v, <= cap
+  int p = 1;
+  while (p * 2 <= cap && v % (p * 2) == 0) p *= 2;
+  return p;
+}
+
+// choose tile + geometry for one conv; returns false if no MFMA config fits
+static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out) {
+  const int order_wide[] = {TILE_256x128, TILE_128x64, TILE_64x64};
+  const int order_narrow[] = {TILE_256x64, TILE_128x64, TILE_64x64};
+  const int* order = a.Cout > 64 ? order_wide : order_narrow;
+  int best = -1;
+  ConvArgs best_a = a;
+  for (int k = 0; k < 3; ++k) {
+    const int tile = order[k];
+    if (stride == 2 && tile != TILE_64x64) continue;
+    const ConvTileInfo ti = conv_tile_info(tile);
+    ConvArgs c = a;
+    const int TW = pow2_divisor(a.Wo, 16);
+    const int TH = pow2_divisor(a.Ho, std::max(1, ti.BM / TW));
+    const int TB = ti.BM / (TW * TH);
+    c.tw_log2 = ilog2(TW); c.th_log2 = ilog2(TH); c.tb_log2 = ilog2(TB);
+    c.tiles_x = a.Wo / TW; c.tiles_y = a.Ho / TH;
+    c.m_tiles = c.tiles_x * c.tiles_y * ((a.B + TB - 1) / TB);
+    if (conv_lds_bytes(dtype, tile, ks, stride, c) == 0) continue;
+    const int n_tiles = (c.nblocks * 32 + ti.BN - 1) / ti.BN;
+    best = tile; best_a = c;
+    if ((long long)c.m_tiles * n_tiles >= 512) break;
+  }
+  if (best < 0) return false;
+  a = best_a;
+  tile_out = best;
+  return true;
+}
+
+struct ConvSpec {
+  const ConvW* w;
+  Tensor x0, x1;       // x1.p == nullptr / C == 0: single source
+  bool up = false;
+  int stride = 1;
+  const float* gn_scale = nullptr; const float* gn_shift = nullptr;
+  bool swish = false;
+  const float* film = nullptr; int film_bs = 0;
+  const float* resid = nullptr; int resid_ld = 0;
+  Tensor out;
+};
+
+static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
+  ConvArgs a{};
+  a.src0 = s.x0.p; a.C0 = s.x0.C;
+  a.src1 = s.x1.C ? s.x1.p : nullptr; a.C1 = s.x1.C;
+  a.B = ex->B; a.Hs = s.x0.H; a.Ws = s.x0.W; a.up = s.up ? 1 : 0;
+  a.Ho = s.out.H; a.Wo = s.out.W;
+  a.gn_scale = s.gn_scale; a.gn_shift = s.gn_shift; a.swish = s.swish ? 1 : 0;
+  a.scalar_stage = ((a.C0 & 3) || (a.C1 & 3)) ? 1 : 0;
+  a.wpack = s.w->pack; a.bias = s.w->bias;
+  a.film = s.film; a.film_bs = s.film_bs;
+  a.resid = s.resid; a.resid_ld = s.resid_ld;
+  a.out = s.out.p; a.out_ld = s.out.C; a.Cout = s.w->cout;
+  a.nblocks = s.w->nblocks; a.kchunks = s.w->kchunks;
+  if (a.C0 + a.C1 != s.w->cin) return fail(DSX_ERR_INVALID, "conv channel mismatch");
+  const int dtype = ex->m->dtype, ks = s.w->ks, stride = s.stride;
+  int tile = -1;
+  const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
+  ex->launches++;
+  if (ex->sizing) return DSX_OK;
+  if (mfma_ok) {
+    ex->ops.push_back([=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
+  } else {
+    if (!s.w->naive)
+      return fail(DSX_ERR_INVALID,
+                  "no MFMA tile fits conv %dx%d (%dx%d out, B=%d); set DSX_CONV_IMPL=naive", ks, ks,
+                  a.Ho, a.Wo, a.B);
+    NaiveConvArgs na{};
+    na.c = a; na.w = s.w->naive; na.ks = ks; na.stride = stride; na.sigmoid_out = 0;
+    ex->ops.push_back([=](hipStream_t st) { return launch_conv_naive(na, st); });
+  }
+  return DSX_OK;
+}
+
+static void plan_stats(dsx_exec* ex, const Tensor& t) {
+  StatInfo& si = ex->stats[t.id];
+  if (si.planned) return;
+  const int HW = t.H * t.W;
+  int nchunk = std::max(1, 512 / ex->B);
+  nchunk = std::min(nchunk, std::max(1, HW / 16));
+  nchunk = std::min(nchunk, 64);
+  si.nchunk = nchunk;
+  si.part = (double*)ws_alloc(ex, (size_t)ex->B * nchunk * t.C * 2 * sizeof(double));
+  si.planned = true;
+  ex->launches++;
+  if (ex->sizing) return;
+  const float* x = t.p; double* part = si.part;
+  const int B = ex->B, C = t.C;
+  ex->ops.push_back([=](hipStream_t st) { return launch_chan_stats(x, B, HW, C, nchunk, part, st); });
+}
+
+// GroupNorm over cat(t0, t1) -> device scale/shift [B][C]
+static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* t1, float** scale, float** shift) {
+  plan_stats(ex, t0);
+  if (t1) plan_stats(ex, *t1);
+  const int C = t0.C + (t1 ? t1->C : 0);
+  *scale = (float*)ws_alloc(ex, (size_t)ex->B * C * sizeof(float));
+  *shift = (float*)ws_alloc(ex, (size_t)ex->B * C * sizeof(float));
+  ex->launches++;
+  if (ex->sizing) return;
+  GnFinArgs a{};
+  a.part0 = ex->stats[t0.id].part; a.C0 = t0.C; a.nchunk0 = ex->stats[t0.id].nchunk;
+  a.part1 = t1 ? ex->stats[t1->id].part : nullptr; a.C1 = t1 ? t1->C : 0;
+  a.nchunk1 = t1 ? ex->stats[t1->id].nchunk : 0;
+  a.B = ex->B; a.groups = ex->m->cfg.norm_groups; a.count = (double)t0.H * t0.W;
+  a.gamma = g.gamma; a.beta = g.beta; a.eps = 1e-5f;
+  a.scale = *scale; a.shift = *shift;
+  ex->ops.push_back([=](hipStream_t st) { return launch_gn_finalize(a, st); });
+}
+
+static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tensor* x1, Tensor& y) {
+  int rc;
+  const int H = x0.H, W = x0.W;
+  float *s1, *h1, *s2, *h2;
+  plan_gn(ex, md.gn1, x0, x1, &s1, &h1);
+  Tensor h = new_tensor(ex, md.cout, H, W);
+  ConvSpec c1{};
+  c1.w = &md.conv1; c1.x0 = x0; if (x1) c1.x1 = *x1;
+  c1.gn_scale = s1; c1.gn_shift = h1; c1.swish = true;
+  if (md.film_off >= 0 && !ex->sizing) { c1.film = ex->film + md.film_off; c1.film_bs = ex->m->F; }
+  c1.out = h;
+  if ((rc = plan_conv(ex, c1))) return rc;
+  plan_gn(ex, md.gn2, h, nullptr, &s2, &h2);
+  Tensor r;
+  if (md.has_res) {
+    r = new_tensor(ex, md.cout, H, W);
+    ConvSpec cr{};
+    cr.w = &md.res; cr.x0 = x0; if (x1) cr.x1 = *x1; cr.out = r;
+    if ((rc = plan_conv(ex, cr))) return rc;
+  } else {
+    r = x0;
+  }
+  Tensor o = new_tensor(ex, md.cout, H, W);
+  ConvSpec c2{};
+  c2.w = &md.conv2; c2.x0 = h; c2.gn_scale = s2; c2.gn_shift = h2; c2.swish = true;
+  c2.resid = r.p; c2.resid_ld = md.cout; c2.out = o;
+  if ((rc = plan_conv(ex, c2))) return rc;
+  if (!md.attn) { y = o; return DSX_OK; }
+  // SelfAttention (unet.py:113-142)
+  float *sa, *ha;
+  plan_gn(ex, md.gna, o, nullptr, &sa, &ha);
+  const int C = md.cout, L = H * W, B = ex->B;
+  Tensor qkv = new_tensor(ex, 3 * C, H, W);
+  ConvSpec cq{};
+  cq.w = &md.qkv; cq.x0 = o; cq.gn_scale = sa; cq.gn_shift = ha; cq.out = qkv;
+  if ((rc = plan_conv(ex, cq))) return rc;
+  float* S = (float*)ws_alloc(ex, (size_t)B * L * L * sizeof(float));
+  Tensor av = new_tensor(ex, C, H, W);
+  ex->launches += 3;
+  if (!ex->sizing) {
+    BgemmArgs g1{};
+    g1.A = qkv.p; g1.lda = 3 * C; g1.sA = (long long)L * 3 * C;
+    g1.Bm = qkv.p + C; g1.ldb = 3 * C; g1.sB = g1.sA; g1.b_kmajor = 0;
+    g1.Cm = S; g1.ldc = L; g1.sC = (long long)L * L;
+    g1.M = L; g1.N = L; g1.K = C; g1.batch = B; g1.div = sqrtf((float)C);
+    ex->ops.push_back([=](hipStream_t st) { return launch_bgemm(g1, st); });
+    ex->ops.push_back([=](hipStream_t st) { return launch_softmax_rows(S, (long long)B * L, L, st); });
+    BgemmArgs g2{};
+    g2.A = S; g2.lda = L; g2.sA = (long long)L * L;
+    g2.Bm = qkv.p + 2 * C; g2.ldb = 3 * C; g2.sB = (long long)L * 3 * C; g2.b_kmajor = 1;
+    g2.Cm = av.p; g2.ldc = C; g2.sC = (long long)L * C;
+    g2.M = L; g2.N = C; g2.K = L; g2.batch = B; g2.div = 1.0f;
+    ex->ops.push_back([=](hipStream_t st) { return launch_bgemm(g2, st); });
+  }
+  Tensor o2 = new_tensor(ex, C, H, W);
+  ConvSpec co{};
+  co.w = &md.out; co.x0 = av; co.resid = o.p; co.resid_ld = C; co.out = o2;
+  if ((rc = plan_conv(ex, co))) return rc;
+  y = o2;
+  return DSX_OK;
+}
+
+static int build_plan(dsx_exec* ex) {
+  dsx_model* m = ex->m;
+  ex->ws_used = 0;
+  ex->ops.clear();
+  ex->stats.clear();
+  ex->launches = 0;
+  const int B = ex->B;
+  ex->step_ctr = (int*)ws_alloc(ex, 256);
+  ex->time_buf = (float*)ws_alloc(ex, (size_t)B * sizeof(float));
+  ex->film = m->F ? (float*)ws_alloc(ex, (size_t)B * m->F * sizeof(float)) : nullptr;
+  ex->in_cond = Tensor();
+  if (ex->cond_c) ex->in_cond = new_tensor(ex, ex->cond_c, ex->H, ex->W);
+  ex->in_x = new_tensor(ex, ex->x_c, ex->H, ex->W);
+  std::vector<Tensor> feats;
+  Tensor x;
+  int rc;
+  for (auto& md : m->mods) {
+    if (md.kind == 0) {
+      Tensor o = new_tensor(ex, md.cout, ex->H, ex->W);
+      ConvSpec c{};
+      c.w = &md.conv;
+      if (ex->cond_c) { c.x0 = ex->in_cond; c.x1 = ex->in_x; } else c.x0 = ex->in_x;
+      c.out = o;
+      if ((rc = plan_conv(ex, c))) return rc;
+      x = o; feats.push_back(x);
+    } else if (md.kind == 2) {
+      if ((x.H & 1) || (x.W & 1)) return fail(DSX_ERR_INVALID, "H and W must be divisible by 2^(levels-1)");
+      Tensor o = new_tensor(ex, md.cout, x.H / 2, x.W / 2);
+      ConvSpec c{};
+      c.w = &md.conv; c.x0 = x; c.stride = 2; c.out = o;
+      if ((rc = plan_conv(ex, c))) return rc;
+      x = o; feats.push_back(x);
+    } else if (md.kind == 3) {
+      Tensor o = new_tensor(ex, md.cout, x.H * 2, x.W * 2);
+      ConvSpec c{};
+      c.w = &md.conv; c.x0 = x; c.up = true; c.out = o;
+      if ((rc = plan_conv(ex, c))) return rc;
+      x = o;
+    } else if (md.kind == 1) {
+      Tensor y;
+      if (md.section == 2) {
+        Tensor skip = feats.back();
+        feats.pop_back();
+        if (skip.H != x.H || skip.W != x.W || skip.C != md.skip) return fail(DSX_ERR_INVALID, "skip mismatch");
+        if ((rc = plan_res(ex, md, x, &skip, y))) return rc;
+      } else {
+        if ((rc = plan_res(ex, md, x, nullptr, y))) return rc;
+      }
+      x = y;
+      if (md.section == 0) feats.push_back(x);
+    } else {
+      float *s, *h;
+      plan_gn(ex, md.gn1, x, nullptr, &s, &h);
+      Tensor o = new_tensor(ex, md.cout, x.H, x.W);
+      ConvSpec c{};
+      c.w = &md.conv; c.x0 = x; c.gn_scale = s; c.gn_shift = h; c.swish = true; c.out = o;
+      if ((rc = plan_conv(ex, c))) return rc;
+      x = o;
+    }
+  }
+  ex->out = x;
+  return DSX_OK;
+}
+
+extern "C" int dsx_exec_create(dsx_model* m, int B, int H, int W, int cond_channels, dsx_exec** out) {
+  if (!m || !out || B < 1 || H < 1 || W < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  if (!m->finalized) return fail(DSX_ERR_STATE, "dsx_model_finalize must precede dsx_exec_create");
+  if (cond_channels < 0 || cond_channels >= m->cfg.in_channel) return fail(DSX_ERR_INVALID, "bad cond_channels");
+  HIP_TRY(conv_init());
+  dsx_exec* ex = new dsx_exec();
+  ex->m = m; ex->B = B; ex->H = H; ex->W = W;
+  ex->cond_c = cond_channels; ex->x_c = m->cfg.in_channel - cond_channels;
+  ex->sizing = true;
+  int rc = build_plan(ex);
+  if (rc) { delete ex; return rc; }
+  ex->ws_bytes = ex->ws_used + 4096;
+  hipError_t e = hipMalloc((void**)&ex->ws, ex->ws_bytes);
+  if (e != hipSuccess) {
+    delete ex;
+    return fail(DSX_ERR_HIP, "hipMalloc(%zu) for the activation workspace failed: %s", ex->ws_bytes,
+                hipGetErrorString(e));
+  }
+  ex->sizing = false;
+  rc = build_plan(ex);
+  if (rc) { (void)hipFree(ex->ws); delete ex; return rc; }
+  e = hipMemset(ex->step_ctr, 0, 256);
+  if (e != hipSuccess) { (void)hipFree(ex->ws); delete ex; return fail(DSX_ERR_HIP, "hipMemset failed"); }
+  *out = ex;
+  return DSX_OK;
+}
+
+extern "C" void dsx_exec_destroy(dsx_exec* ex) {
+  if (!ex) return;
+  if (ex->graph_exec) (void)hipGraphExecDestroy(ex->graph_exec);
+  if (ex->graph) (void)hipGraphDestroy(ex->graph);
+  if (ex->table) (void)hipFree(ex->table);
+  if (ex->tp_w) (void)hipFree(ex->tp_w);
+  if (ex->ws) (void)hipFree(ex->ws);
+  delete ex;
+}
+extern "C" size_t dsx_exec_workspace_bytes(const dsx_exec* ex) { return ex ? ex->ws_bytes : 0; }
+extern "C" int dsx_exec_num_launches(const dsx_exec* ex) { return ex ? ex->launches : 0; }
+
+// time embedding + UNet body on `st`; inputs already in ex->in_cond / ex->in_x
+static int run_unet(dsx_exec* ex, bool from_table, int n_time, hipStream_t st) {
+  dsx_model* m = ex->m;
+  if (m->cfg.with_time_emb) {
+    TembArgs t{};
+    t.flavour = m->cfg.flavour; t.B = ex->B; t.n_time = n_time;
+    t.time = from_table ? nullptr : ex->time_buf;
+    t.table = ex->table; t.step_ctr = ex->step_ctr;
+    t.inner = m->cfg.inner_channel; t.freq = m->d_freq;
+    t.w1 = m->d_w1; t.b1 = m->d_b1; t.w2 = m->d_w2; t.b2 = m->d_b2;
+    t.wf = m->d_wf; t.bf = m->d_bf; t.F = m->F; t.film = ex->film;
+    HIP_TRY(launch_temb(t, st));
+  }
+  for (auto& op : ex->ops) HIP_TRY(op(st));
+  return DSX_OK;
+}
+
+static int load_inputs(dsx_exec* ex, const float* cond_nchw, const float* x_nchw, int x_total_c,
+                       int x_c_off, hipStream_t st);
+
+extern "C" int dsx_unet_forward(dsx_exec* ex, const float* x, const float* time, int n_time, float* y,
+                                void* stream) {
+  if (!ex || !x || !y) return fail(DSX_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  dsx_model* m = ex->m;
+  if (m->cfg.with_time_emb) {
+    if (!time || !(n_time == 1 || n_time == ex->B)) return fail(DSX_ERR_INVALID, "n_time must be 1 or B");
+    HIP_TRY(hipMemcpyAsync(ex->time_buf, time, (size_t)n_time * 4, hipMemcpyDeviceToDevice, st));
+  }
+  // x is (B, in_channel, H, W): channels [0,cond_c) feed the cond tensor, the rest the state tensor
+  int rc = load_inputs(ex, ex->cond_c ? x : nullptr, x, m->cfg.in_channel, ex->cond_c, st);
+  if (rc) return rc;
+  if ((rc = run_unet(ex, false, n_time, st))) return rc;
+  HIP_TRY(launch_nhwc_to_nchw(ex->out.p, y, ex->B, ex->out.C, ex->H, ex->W, st));
+  return DSX_OK;
+}
+
+static int load_inputs(dsx_exec* ex, const float* cond_nchw, const float* x_nchw, int x_total_c,
+                       int x_c_off, hipStream_t st) {
+  const int HW = ex->H * ex->W;
+  if (ex->cond_c) {
+    if (!cond_nchw) return fail(DSX_ERR_INVALID, "this executor was created with cond_channels > 0");
+    const int ctot = (cond_nchw == x_nchw) ? x_total_c : ex->cond_c;
+    HIP_TRY(dsx::launch_nchw_slice_to_nhwc(cond_nchw, ex->in_cond.p, ex->B, ex->cond_c, ctot, 0, HW, st));
+  }
+  HIP_TRY(dsx::launch_nchw_slice_to_nhwc(x_nchw, ex->in_x.p, ex->B, ex->x_c, x_total_c, x_c_off, HW, st));
+  return DSX_OK;
+}
+
+// ------------------------------------------------------------------ sampler
+static int ensure_table(dsx_exec* ex, const dsx_step_table* tab) {
+  const int T = tab->n_steps;
+  if (T > ex->table_cap) {
+    if (ex->graph_exec) { (void)hipGraphExecDestroy(ex->graph_exec); ex->graph_exec = nullptr; }
+    if (ex->graph) { (void)hipGraphDestroy(ex->graph); ex->graph = nullptr; }
+    if (ex->table) (void)hipFree(ex->table);
+    ex->table = nullptr;
+    HIP_TRY(hipMalloc((void**)&ex->table, (size_t)6 * T * sizeof(float)));
+    ex->table_cap = T;
+  }
+  ex->table_host.assign((size_t)6 * T, 0.f);
+  const float* cols[6] = {tab->tcond, tab->a, tab->b, tab->c1, tab->c2, tab->sigma};
+  for (int k = 0; k < 6; ++k)
+    if (cols[k]) memcpy(ex->table_host.data() + (size_t)k * T, cols[k], (size_t)T * 4);
+  return DSX_OK;
+}
+
+static int enqueue_step(dsx_exec* ex, const dsx_step_table* tab, const float* noise, uint64_t seed,
+                        hipStream_t st) {
+  int rc = run_unet(ex, true, 1, st);
+  if (rc) return rc;
+  UpdateArgs u{};
+  u.x = ex->in_x.p; u.net = ex->out.p; u.noise = noise; u.seed = seed;
+  u.tab = ex->table; u.n_steps = tab->n_steps; u.step_ctr = ex->step_ctr;
+  u.predict_eps = tab->predict_eps; u.clip = tab->clip;
+  u.B = ex->B; u.C = ex->x_c; u.H = ex->H; u.W = ex->W;
+  HIP_TRY(launch_update(u, st));
+  HIP_TRY(launch_advance(ex->step_ctr, st));
+  return DSX_OK;
+}
+
+extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const float* cond, float* x,
+                               const float* noise, uint64_t seed, const int32_t* snap_steps, int n_snap,
+                               float* snaps, int use_graph, void* stream) {
+  if (!ex || !tab || !x || tab->n_steps < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  if (!tab->tcond || !tab->c1 || !tab->c2 || !tab->sigma || (tab->predict_eps && (!tab->a || !tab->b)))
+    return fail(DSX_ERR_INVALID, "step table columns missing");
+  if (ex->out.C != ex->x_c)
+    return fail(DSX_ERR_INVALID, "UNet out_channel (%d) must equal the state channels (%d)", ex->out.C, ex->x_c);
+  if (n_snap > 0 && (!snap_steps || !snaps)) return fail(DSX_ERR_INVALID, "snapshot arrays missing");
+  hipStream_t st = (hipStream_t)stream;
+  const int T = tab->n_steps;
+  int rc = ensure_table(ex, tab);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(ex->table, ex->table_host.data(), (size_t)6 * T * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(ex->step_ctr, 0, 4, st));
+  if ((rc = load_inputs(ex, cond, x, ex->x_c, 0, st))) return rc;
+
+  const size_t snap_elems = (size_t)ex->B * ex->x_c * ex->H * ex->W;
+  bool graph_ok = false;
+  if (use_graph) {
+    // the captured step bakes in: n_steps (table stride), mode flags, noise pointer, seed
+    std::vector<float> sig = {(float)T, (float)tab->predict_eps, (float)tab->clip};
+    uint64_t np = (uint64_t)(uintptr_t)noise;
+    float f[4];
+    memcpy(f, &np, 8); memcpy(f + 2, &seed, 8);
+    sig.insert(sig.end(), f, f + 4);
+    if (!ex->graph_exec || sig.size() != ex->graph_sig.size() ||
+        memcmp(sig.data(), ex->graph_sig.data(), sig.size() * 4)) {
+      if (ex->graph_exec) { (void)hipGraphExecDestroy(ex->graph_exec); ex->graph_exec = nullptr; }
+      if (ex->graph) { (void)hipGraphDestroy(ex->graph); ex->graph = nullptr; }
+      hipStream_t cs;
+      HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        rc = enqueue_step(ex, tab, noise, seed, cs);
+        hipError_t e2 = hipStreamEndCapture(cs, &ex->graph);
+        if (rc == DSX_OK && e2 == hipSuccess) e2 = hipGraphInstantiate(&ex->graph_exec, ex->graph, nullptr, nullptr, 0);
+        if (rc != DSX_OK || e2 != hipSuccess) {
+          (void)hipGetLastError();
+          if (ex->graph) { (void)hipGraphDestroy(ex->graph); ex->graph = nullptr; }
+          ex->graph_exec = nullptr;
+        }
+      } else {
+        (void)hipGetLastError();
+      }
+      (void)hipStreamDestroy(cs);
+      if (ex->graph_exec) ex->graph_sig = sig;
+      else if (rc != DSX_OK) return rc;
+    }
+    graph_ok = ex->graph_exec != nullptr;
+    if (!graph_ok) return fail(DSX_ERR_HIP, "hipGraph capture of the sampling step failed");
+  }
+  int snap_i = 0;
+  for (int s = 0; s < T; ++s) {
+    if (graph_ok) HIP_TRY(hipGraphLaunch(ex->graph_exec, st));
+    else if ((rc = enqueue_step(ex, tab, noise, seed, st))) return rc;
+    while (snap_i < n_snap && snap_steps[snap_i] == s) {
+      HIP_TRY(launch_nhwc_to_nchw(ex->in_x.p, snaps + (size_t)snap_i * snap_elems, ex->B, ex->x_c, ex->H,
+                                  ex->W, st));
+      ++snap_i;
+    }
+  }
+  HIP_TRY(launch_nhwc_to_nchw(ex->in_x.p, x, ex->B, ex->x_c, ex->H, ex->W, st));
+  return DSX_OK;
+}
+
+extern "C" int dsx_randn(float* out, int64_t n, uint64_t seed, uint64_t subseq, void* stream) {
+  if (!out || n < 0) return fail(DSX_ERR_INVALID, "bad argument");
+  if (n == 0) return DSX_OK;
+  HIP_TRY(launch_randn(out, n, seed, subseq, (hipStream_t)stream));
+  return DSX_OK;
+}
+
+// ------------------------------------------------------------------ time predictor head
+extern "C" int dsx_time_predictor_set_mask(dsx_exec* ex, const float* w, const float* b) {
+  if (!ex || !w || !b) return fail(DSX_ERR_INVALID, "null argument");
+  const int cin = ex->m->cfg.in_channel;
+  if (ex->out.C != 1) return fail(DSX_ERR_INVALID, "TimePredictor head expects out_channel == 1");
+  const size_t nw = (size_t)49 * cin;
+  std::vector<float> hw(nw);
+  for (int ci = 0; ci < cin; ++ci)
+    for (int t = 0; t < 49; ++t) hw[(size_t)t * cin + ci] = w[(size_t)ci * 49 + t];  // (1,in,7,7) -> [49][in]
+  if (!ex->tp_w) HIP_TRY(hipMalloc((void**)&ex->tp_w, (nw + 64) * 4 + (size_t)ex->B * ex->H * ex->W * 4));
+  ex->tp_b = ex->tp_w + nw;
+  ex->tp_mask = ex->tp_w + nw + 64;
+  HIP_TRY(hipMemcpy(ex->tp_w, hw.data(), nw * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ex->tp_b, b, 4, hipMemcpyHostToDevice));
+  return DSX_OK;
+}
+
+extern "C" int dsx_time_predictor_forward(dsx_exec* ex, const float* x, float* t_out, void* stream) {
+  if (!ex || !x || !t_out) return fail(DSX_ERR_INVALID, "null argument");
+  if (!ex->tp_w) return fail(DSX_ERR_STATE, "dsx_time_predictor_set_mask first");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = load_inputs(ex, nullptr, x, ex->m->cfg.in_channel, 0, st);
+  if (rc) return rc;
+  if ((rc = run_unet(ex, false, 1, st))) return rc;
+  NaiveConvArgs na{};
+  na.c.src0 = ex->in_x.p; na.c.C0 = ex->x_c; na.c.C1 = 0;
+  na.c.B = ex->B; na.c.Hs = ex->H; na.c.Ws = ex->W; na.c.Ho = ex->H; na.c.Wo = ex->W;
+  na.c.bias = ex->tp_b; na.c.out = ex->tp_mask; na.c.out_ld = 1; na.c.Cout = 1;
+  na.w = ex->tp_w; na.ks = 7; na.stride = 1; na.sigmoid_out = 1;
+  HIP_TRY(launch_conv_naive(na, st));
+  HIP_TRY(launch_masked_mean(ex->out.p, ex->tp_mask, ex->B, (long long)ex->H * ex->W, t_out, st));
+  return DSX_OK;
+}
+
+// ------------------------------------------------------------------ tiling (host integer math)
+namespace {
+struct TilePlanner {
+  int64_t D[3], g[3], p[3];
+  int mode;
+  int64_t dim_count(int d) const {  // tiling_manager.py:34-50
+    if (g[d] == 1 && p[d] == 1) return D[d];
+    const int64_t ex = p[d] - g[d];
+    if (mode == DSX_TILING_PAD) return (D[d] + g[d] - 1) / g[d];
+    const int64_t num = D[d] - ex;
+    if (mode == DSX_TILING_SHIFT) return num <= 0 ? 0 : (num + g[d] - 1) / g[d];
+    return num < 0 ? 0 : num / g[d];
+  }
+  int64_t grid_count(int d) const {  // :58-68
+    int64_t n = 1;
+    for (int k = d + 1; k < 3; ++k) n *= dim_count(k);
+    return n;
+  }
+  int64_t total() const { return grid_count(0) * dim_count(0); }
+  int64_t grid_start(int d, int64_t k) const {  // :121-143
+    const int64_t ex = (p[d] - g[d]) / 2;
+    if (g[d] == 1 && p[d] == 1) return k;
+    if (mode == DSX_TILING_PAD) return k * g[d];
+    if (mode == DSX_TILING_TRIM) return k * g[d] + ex;
+    if (k < dim_count(d) - 1) return k * g[d] + ex;
+    return D[d] - g[d] - ex;
+  }
+  void location(int64_t idx, int64_t loc[3]) const {  // :145-154
+    for (int d = 0; d < 3; ++d) {
+      const int64_t gc = grid_count(d);
+      loc[d] = grid_start(d, idx / gc);
+      idx %= gc;
+    }
+  }
+};
+static int make_planner(const int64_t* ds, const int64_t* gs, const int64_t* ps, int mode, TilePlanner& t) {
+  if (!ds || !gs || !ps) return fail(DSX_ERR_INVALID, "null shape");
+  if (mode < 0 || mode > 2) return fail(DSX_ERR_INVALID, "bad tiling mode");
+  for (int d = 0; d < 3; ++d) {
+    t.D[d] = ds[d]; t.g[d] = gs[d]; t.p[d] = ps[d];
+    if (ds[d] < 1 || gs[d] < 1 || ps[d] < gs[d] || ((ps[d] - gs[d]) & 1))  // tiling_manager.py:21-29
+      return fail(DSX_ERR_INVALID, "patch must be >= grid with even padding in dim %d", d);
+  }
+  t.mode = mode;
+  return DSX_OK;
+}
+}  // namespace
+
+extern "C" int64_t dsx_tile_plan(const int64_t data_shape[3], const int64_t grid_shape[3],
+                                 const int64_t patch_shape[3], int mode, int64_t* grid_start,
+                                 int64_t* patch_start, int64_t capacity) {
+  TilePlanner t;
+  int rc = make_planner(data_shape, grid_shape, patch_shape, mode, t);
+  if (rc) return rc;
+  const int64_t n = t.total();
+  if (grid_start || patch_start) {
+    if (capacity < n) return fail(DSX_ERR_INVALID, "capacity %lld < %lld tiles", (long long)capacity, (long long)n);
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t loc[3];
+      t.location(i, loc);
+      for (int d = 0; d < 3; ++d) {
+        if (grid_start) grid_start[i * 3 + d] = loc[d];
+        if (patch_start) patch_start[i * 3 + d] = loc[d] - (t.p[d] - t.g[d]) / 2;
+      }
+    }
+  }
+  return n;
+}
+
+extern "C" int dsx_tile_regions(const int64_t data_shape[3], const int64_t grid_shape[3],
+                                const int64_t patch_shape[3], int mode, int32_t* regions, int64_t capacity) {
+  TilePlanner t;
+  int rc = make_planner(data_shape, grid_shape, patch_shape, mode, t);
+  if (rc) return rc;
+  if (!regions) return fail(DSX_ERR_INVALID, "null regions");
+  const int64_t n = t.total();
+  if (capacity < n) return fail(DSX_ERR_INVALID, "capacity too small");
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t gs[3], vgs[3], vge[3], ps[3];
+    t.location(i, gs);
+    for (int d = 0; d < 3; ++d) {  // tile_stitcher.py:26-56
+      const int64_t ge = gs[d] + t.g[d];
+      ps[d] = gs[d] - (t.p[d] - t.g[d]) / 2;
+      const int64_t pe = ps[d] + t.p[d];
+      vgs[d] = gs[d]; vge[d] = ge;
+      if (mode == DSX_TILING_SHIFT) {
+        if (ps[d] == 0) vgs[d] = 0;
+        if (pe == t.D[d]) vge[d] = t.D[d];
+      }
+    }
+    int32_t* r = regions + i * 8;
+    r[0] = (int32_t)vgs[0]; r[1] = (int32_t)vgs[1]; r[2] = (int32_t)vgs[2];
+    r[3] = (int32_t)(vge[1] - vgs[1]); r[4] = (int32_t)(vge[2] - vgs[2]);
+    r[5] = (int32_t)(vgs[1] - ps[1]); r[6] = (int32_t)(vgs[2] - ps[2]); r[7] = 0;
+  }
+  return DSX_OK;
+}
+
+extern "C" int dsx_tiles_gather(const float* frames, const int64_t data_shape[3], const int64_t patch_shape[3],
+                                const int64_t* patch_start, const int64_t* tile_ids, int64_t count,
+                                float* tiles, void* stream) {
+  if (!frames || !data_shape || !patch_shape || !patch_start || !tiles || count < 0)
+    return fail(DSX_ERR_INVALID, "bad argument");
+  if (count == 0) return DSX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<int> starts((size_t)count * 3);
+  for (int64_t i = 0; i < count; ++i) {
+    const int64_t id = tile_ids ? tile_ids[i] : i;
+    for (int d = 0; d < 3; ++d) starts[i * 3 + d] = (int)patch_start[id * 3 + d];
+    if (starts[i * 3] < 0 || starts[i * 3] >= data_shape[0] || starts[i * 3 + 1] < 0 ||
+        starts[i * 3 + 1] + patch_shape[1] > data_shape[1] || starts[i * 3 + 2] < 0 ||
+        starts[i * 3 + 2] + patch_shape[2] > data_shape[2])
+      return fail(DSX_ERR_INVALID, "tile %lld lies outside the frames", (long long)id);
+  }
+  int* d_starts = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_starts, starts.size() * 4));
+  HIP_TRY(hipMemcpyAsync(d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));  // `starts` is a stack-owned host buffer
+  HIP_TRY(launch_tiles_gather(frames, (int)data_shape[1], (int)data_shape[2], (int)patch_shape[1],
+                              (int)patch_shape[2], d_starts, count, tiles, st));
+  HIP_TRY(hipFree(d_starts));  // synchronises: the gather has finished
+  return DSX_OK;
+}
+
+extern "C" int dsx_stitch(const float* tiles, int64_t count, int C, int ph, int pw, const int32_t* regions,
+                          float* canvas, const int64_t data_shape[3], void* stream) {
+  if (!tiles || !regions || !canvas || !data_shape || count < 0 || C < 1)
+    return fail(DSX_ERR_INVALID, "bad argument");
+  if (count == 0) return DSX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i = 0; i < count; ++i) {
+    const int32_t* r = regions + i * 8;
+    if (r[0] < 0 || r[0] >= data_shape[0] || r[1] < 0 || r[1] + r[3] > data_shape[1] || r[2] < 0 ||
+        r[2] + r[4] > data_shape[2] || r[5] < 0 || r[5] + r[3] > ph || r[6] < 0 || r[6] + r[4] > pw)
+      return fail(DSX_ERR_INVALID, "region %lld out of bounds", (long long)i);
+  }
+  int* d_reg = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_reg, (size_t)count * 32));
+  HIP_TRY(hipMemcpyAsync(d_reg, regions, (size_t)count * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(launch_stitch(tiles, count, C, ph, pw, d_reg, canvas, (int)data_shape[1], (int)data_shape[2], st));
+  HIP_TRY(hipFree(d_reg));  // synchronises: the paste has finished
+  return DSX_OK;
+}

@@ -1,0 +1,205 @@
+/*
+ * dsx.h — C ABI of libdsx.so, the MI355X (gfx950) sampling engine that sits
+ * underneath the DiffSplitting Python entry points.
+ *
+ * The reference (rayanirban/DiffSplitting) has no native/FFI layer: its
+ * boundary is the Python API in model/networks.py:91 (define_G),
+ * model/model.py:63 (DDPM.test) and the sampler classes.  The entry points
+ * below are what a native replacement for that hot path binds; each one cites
+ * the reference interface it replaces.  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions: every function returns 0 on success and a negative dsx_status
+ * on failure; dsx_last_error() returns a thread-local message.  Nothing throws
+ * across the ABI.  "dev" pointers are device (HBM) pointers borrowed from the
+ * caller (e.g. torch.Tensor.data_ptr()); "host" pointers are plain host
+ * memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Calls on one handle are not concurrent; distinct handles may run on distinct
+ * streams concurrently.  One process drives one GPU.
+ */
+#ifndef DSX_H
+#define DSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSX_ABI_VERSION 1
+
+typedef enum dsx_status {
+  DSX_OK = 0,
+  DSX_ERR_INVALID = -1,   /* bad argument / shape the kernels do not support */
+  DSX_ERR_HIP = -2,       /* a HIP runtime call failed (no device, OOM, ...) */
+  DSX_ERR_STATE = -3,     /* call order violated (e.g. forward before finalize) */
+  DSX_ERR_MISSING = -4    /* a parameter was never set */
+} dsx_status;
+
+const char* dsx_last_error(void);
+int dsx_abi_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int dsx_device_count(void);
+
+/* ------------------------------------------------------------------ UNet */
+
+enum { DSX_FLAVOUR_SR3 = 0, DSX_FLAVOUR_DDPM = 1 };
+enum { DSX_DTYPE_F32 = 0, DSX_DTYPE_BF16 = 1 };   /* MFMA operand type; accumulation is always f32 */
+
+/* Mirrors the keyword arguments of UNet.__init__
+ * (model/sr3_modules/unet.py:161-174, model/ddpm_modules/unet.py:150-162). */
+typedef struct dsx_unet_cfg {
+  int32_t flavour;          /* DSX_FLAVOUR_* : gamma (sr3) or t (ddpm) conditioning */
+  int32_t in_channel;
+  int32_t out_channel;
+  int32_t inner_channel;
+  int32_t norm_groups;
+  int32_t n_mults;
+  int32_t channel_mults[8];
+  int32_t n_attn_res;
+  int32_t attn_res[8];
+  int32_t res_blocks;
+  int32_t image_size;       /* only used to place attn_res, as in the reference */
+  int32_t with_time_emb;    /* 0 for the TimePredictor's UNet (time_predictor.py:24-33) */
+} dsx_unet_cfg;
+
+typedef struct dsx_model dsx_model;
+
+/* Host-only: builds the topology and the parameter table.  Works without a GPU. */
+int dsx_model_create(const dsx_unet_cfg* cfg, dsx_model** out);
+void dsx_model_destroy(dsx_model* m);
+
+/* The parameter table uses the reference's state_dict key names relative to
+ * the UNet (e.g. "downs.1.res_block.block1.block.3.weight"), in state_dict
+ * order, so a *_gen.pth (model/model.py:131-173) maps 1:1.  Shapes are the
+ * reference's (OIHW conv weights, [out,in] linears). */
+int dsx_model_num_params(const dsx_model* m);
+int dsx_model_param_info(const dsx_model* m, int index, char* name_buf, int name_cap,
+                         int* ndim, int64_t shape[4]);
+/* Copies one parameter (fp32, reference layout, host memory). */
+int dsx_model_set_param(dsx_model* m, int index, const float* host_data, int64_t numel);
+/* sr3 only: the PositionalEncoding frequency table exp(-ln(1e4)*k/(d/2)),
+ * k<d/2 (sr3 unet.py:24-28); optional — computed with expf() if never set. */
+int dsx_model_set_posenc_freq(dsx_model* m, const float* host_freq, int count);
+/* Repacks all weights into the kernels' layouts (MFMA fragment order, fp32 or
+ * bf16) and uploads them to the current HIP device. */
+int dsx_model_finalize(dsx_model* m, int compute_dtype);
+/* Algorithmic FLOPs (2*MAC of conv/linear/attention contractions) of one
+ * forward of one image of H x W. */
+double dsx_model_flops(const dsx_model* m, int H, int W);
+
+/* --------------------------------------------------------------- executor */
+
+typedef struct dsx_exec dsx_exec;
+
+/* Plans one UNet forward for a fixed (B,H,W): kernel list, tile shapes,
+ * activation workspace (hipMalloc'ed once, sized for 288 GB parts: no reuse
+ * games).  cond_channels > 0 declares that the first conv reads its input as
+ * two tensors (cond, x) instead of a materialised torch.cat
+ * (sr3 diffusion.py:157-158). */
+int dsx_exec_create(dsx_model* m, int B, int H, int W, int cond_channels, dsx_exec** out);
+void dsx_exec_destroy(dsx_exec* ex);
+size_t dsx_exec_workspace_bytes(const dsx_exec* ex);
+int dsx_exec_num_launches(const dsx_exec* ex);
+
+/* One UNet forward: replaces denoise_fn(x, t)
+ * (sr3 unet.py:235-259 / ddpm unet.py:220-243).
+ *   x_nchw_dev : (B, in_channel, H, W) fp32, NCHW as the reference passes it
+ *   time_dev   : n_time fp32 values; n_time == B (sr3 gamma (B,1), ddpm t (B,))
+ *                or 1 (InDI's single scalar, indi.py:65); NULL when
+ *                with_time_emb == 0
+ *   y_nchw_dev : (B, out_channel, H, W) fp32 */
+int dsx_unet_forward(dsx_exec* ex, const float* x_nchw_dev, const float* time_dev, int n_time,
+                     float* y_nchw_dev, void* stream);
+
+/* TimePredictor head (time_predictor.py:35-44): relu(unet(x)) * sigmoid(conv7x7(x)),
+ * masked mean per image.  mask_w: (1,in,7,7) host fp32, mask_b: (1,) host. */
+int dsx_time_predictor_set_mask(dsx_exec* ex, const float* mask_w_host, const float* mask_b_host);
+int dsx_time_predictor_forward(dsx_exec* ex, const float* x_nchw_dev, float* t_out_dev, void* stream);
+
+/* ---------------------------------------------------------------- sampler */
+
+/* One row per reverse step, in execution order (host-computed, fp32, so that
+ * "schedule indexing" is bit-exact with the reference):
+ *   tcond : value fed to the UNet's time embedding
+ *           (sr3: sqrt_alphas_cumprod_prev[i+1], diffusion.py:153-154;
+ *            ddpm: float(i); InDI: fp32(cur_t), indi.py:65)
+ *   predict_eps = 1 (SR3/DDPM, diffusion.py:141-175):
+ *           x0 = a*x - b*eps ; clamp(+-1) if clip ; x <- (c1*x0 + c2*x) + sigma*z
+ *   predict_eps = 0 (InDI, indi.py:62-69):
+ *           x <- (c1*net + c2*x) + sigma*z      (a, b ignored)
+ * Every product and sum is rounded separately, like the reference's op
+ * sequence (no FMA contraction). */
+typedef struct dsx_step_table {
+  int32_t n_steps;
+  int32_t predict_eps;
+  int32_t clip;
+  const float* tcond;   /* host, n_steps */
+  const float* a;
+  const float* b;
+  const float* c1;
+  const float* c2;
+  const float* sigma;
+} dsx_step_table;
+
+/* Runs the whole reverse loop on `stream` without host synchronisation:
+ * replaces GaussianDiffusion.p_sample_loop (sr3 diffusion.py:177-203,
+ * ddpm diffusion.py:205-237) and InDI.inference's loop (indi.py:86-90).
+ *   cond_nchw_dev : (B, cond_channels, H, W) or NULL (must match dsx_exec_create)
+ *   x_nchw_dev    : (B, C, H, W) in: initial state (the caller draws it, as
+ *                   diffusion.py:194 / indi.py:82 do); out: final state, FULL batch
+ *   noise_nchw_dev: NULL -> device Philox normals keyed by (seed, step);
+ *                   else (n_steps, B, C, H, W) injected draws in the
+ *                   reference's draw order (parity mode)
+ *   snap_steps    : host array of step ordinals (0-based) after which the
+ *                   state is copied to snap_nchw_dev[k] (B,C,H,W each); may be NULL
+ *   use_graph     : 1 = capture one step into a hipGraph and replay it */
+int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab,
+                    const float* cond_nchw_dev, float* x_nchw_dev,
+                    const float* noise_nchw_dev, uint64_t seed,
+                    const int32_t* snap_steps, int n_snap, float* snap_nchw_dev,
+                    int use_graph, void* stream);
+
+/* Fills n fp32 values with N(0,1) from the engine's Philox4x32-10 stream. */
+int dsx_randn(float* out_dev, int64_t n, uint64_t seed, uint64_t subsequence, void* stream);
+
+/* ----------------------------------------------------------------- tiling */
+
+enum { DSX_TILING_TRIM = 0, DSX_TILING_PAD = 1, DSX_TILING_SHIFT = 2 };  /* tiling_manager.py:6-12 */
+
+/* Tile enumeration for data (N,H,W), replaces TileIndexManager
+ * (data/tiling_manager.py:34-154) as SplitDatasetTiledPred sets it up
+ * (data/split_dataset_tiledpred.py:9-24).  Host-only integer math.
+ * Returns the tile count; if grid_start/patch_start are non-NULL they
+ * receive count*3 entries (n, y, x). */
+int64_t dsx_tile_plan(const int64_t data_shape[3], const int64_t grid_shape[3],
+                      const int64_t patch_shape[3], int tiling_mode,
+                      int64_t* grid_start, int64_t* patch_start, int64_t capacity);
+
+/* Valid region of every tile (tile_stitcher.py:26-56): dst start (n,y,x),
+ * extent (1,h,w) and the offset (y,x) inside the tile.  8 int32 per tile:
+ * {n, y, x, h, w, ry, rx, 0}. */
+int dsx_tile_regions(const int64_t data_shape[3], const int64_t grid_shape[3],
+                     const int64_t patch_shape[3], int tiling_mode,
+                     int32_t* regions, int64_t capacity);
+
+/* Cuts tiles out of frames on the device: frames (N,H,W) fp32 ->
+ * tiles (count, ph, pw) for the tiles listed in tile_ids (host array).
+ * Replaces the per-item crop of SplitDataset.__getitem__
+ * (data/split_dataset.py:237-246) for batch dispatch. */
+int dsx_tiles_gather(const float* frames_dev, const int64_t data_shape[3],
+                     const int64_t patch_shape[3], const int64_t* patch_start_host,
+                     const int64_t* tile_ids_host, int64_t count, float* tiles_dev, void* stream);
+
+/* Pastes the valid region of `count` predicted tiles (count, C, ph, pw) into
+ * the zero-initialised canvas (N,H,W,C), channel-last: replaces
+ * stitch_predictions (data/tile_stitcher.py:10-81).  regions as from
+ * dsx_tile_regions for exactly these tiles. */
+int dsx_stitch(const float* tiles_dev, int64_t count, int C, int ph, int pw,
+               const int32_t* regions_host, float* canvas_dev, const int64_t data_shape[3],
+               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSX_H */

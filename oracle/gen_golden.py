@@ -188,8 +188,13 @@ for cfgname in ("sr_sr3_16_128", "sr_sr3_64_512", "sr_ddpm_16_128"):
               res_blocks=u["res_blocks"], dropout=u["dropout"],
               image_size=raw["model"]["diffusion"]["image_size"])
     keylists[cfgname] = [("denoise_fn." + k, s) for k, s in key_shapes(net)]
+# the hyper-parameters the key lists were built from (model section of each config)
+modelcfgs = {}
+for cfgname in keylists:
+    raw = cases.load_config_json(os.path.join(REF, "config", cfgname + ".json"))
+    modelcfgs[cfgname] = raw["model"]
 with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
-    json.dump(keylists, f)
+    json.dump({"keys": keylists, "model": modelcfgs}, f)
 print("state_dict_keys.json:", {k: len(v) for k, v in keylists.items()})
 
 # ---------------------------------------------------------------- tiling

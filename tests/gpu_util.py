@@ -1,0 +1,41 @@
+"""Shared helpers for the -m gpu parity tests (engine vs oracle)."""
+import numpy as np
+import torch
+
+from oracle import cases
+
+
+class DrawRecorder:
+    """randn(shape) callable that records every draw, in draw order."""
+
+    def __init__(self, seed):
+        self.gen = torch.Generator().manual_seed(seed)
+        self.draws = []
+
+    def __call__(self, shape):
+        t = torch.randn(tuple(shape), generator=self.gen)
+        self.draws.append(t)
+        return t
+
+
+def build_engine(cfg, flavour, sd, prefix="", dtype="f32", with_time_emb=True):
+    from diffsplitting_amd import engine
+    c = engine.make_cfg(flavour, cfg["in_channel"], cfg["out_channel"], cfg["inner_channel"],
+                        cfg["norm_groups"], cfg["channel_mults"], cfg["attn_res"], cfg["res_blocks"],
+                        cfg["image_size"], with_time_emb)
+    eng = engine.UNetEngine(c, flavour)
+    eng.load_state_dict(sd, prefix)
+    eng.finalize(dtype)
+    return eng
+
+
+def psnr(ref, x):
+    ref = np.asarray(ref, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    mse = np.mean((ref - x) ** 2)
+    rng = ref.max() - ref.min()
+    return 20 * np.log10(rng / np.sqrt(mse + 1e-30))
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))

@@ -1,0 +1,312 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Runs on the MI355X box only (`-m gpu`).
+
+Tolerances (north_star): fp32 path <= 1e-3 max-abs per pixel vs the reference
+CPU loop on identical weights + identical injected noise; bf16 operands are
+judged by PSNR against the fp32 oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, samplers, tiling
+from oracle.unet import time_predictor_forward, unet_forward
+from tests.gpu_util import DrawRecorder, build_engine, maxabs, psnr
+from tests.util import golden_state_dict, load_golden
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+FP32_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+# ----------------------------------------------------------------------------- UNet forward
+@pytest.mark.parametrize("name", ["ddpm_tiny", "sr3_tiny", "joint_32", "hagen_64", "sr3_128"])
+def test_unet_forward_fp32(name, dev):
+    sd, g = golden_state_dict("unet_" + name)
+    case = cases.UNET_CASES[name]
+    x, t = cases.make_unet_inputs(name)
+    eng = build_engine(case["cfg"], case["flavour"], sd)
+    y = eng.forward(x.to(dev), t.to(dev).float()).cpu().numpy()
+    ref = unet_forward(sd, case["cfg"], case["flavour"], x, t).numpy()
+    assert maxabs(y, ref) <= FP32_TOL, f"vs oracle: {maxabs(y, ref)}"
+    assert maxabs(y, g["y"]) <= FP32_TOL, f"vs golden: {maxabs(y, g['y'])}"
+    print(f"\n{name}: max|hip-oracle| = {maxabs(y, ref):.3e}  launches={eng.num_launches(*x.shape[:1], *x.shape[2:])}")
+
+
+def test_unet_forward_cond_split(dev):
+    """cond/x passed as two tensors (no torch.cat) gives the same result as the concatenated input."""
+    name = "sr3_tiny"
+    sd, g = golden_state_dict("unet_" + name)
+    case = cases.UNET_CASES[name]
+    x, t = cases.make_unet_inputs(name)
+    eng = build_engine(case["cfg"], case["flavour"], sd)
+    y = eng.forward(x.to(dev), t.to(dev), cond_channels=3).cpu().numpy()
+    assert maxabs(y, g["y"]) <= FP32_TOL
+
+
+@pytest.mark.parametrize("name", ["sr3_tiny", "hagen_64", "sr3_128"])
+def test_unet_forward_bf16_psnr(name, dev):
+    sd, g = golden_state_dict("unet_" + name)
+    case = cases.UNET_CASES[name]
+    x, t = cases.make_unet_inputs(name)
+    eng = build_engine(case["cfg"], case["flavour"], sd, dtype="bf16")
+    y = eng.forward(x.to(dev), t.to(dev).float()).cpu().numpy()
+    p = psnr(g["y"], y)
+    print(f"\n{name}: bf16 PSNR vs fp32 oracle = {p:.1f} dB, max-abs {maxabs(y, g['y']):.3e}")
+    assert p > 35.0
+
+
+def test_unet_forward_naive_conv_crosscheck(dev, monkeypatch):
+    """The plain direct-conv kernel (DSX_CONV_IMPL=naive) and the MFMA kernel agree."""
+    monkeypatch.setenv("DSX_CONV_IMPL", "naive")
+    name = "ddpm_tiny"
+    sd, g = golden_state_dict("unet_" + name)
+    case = cases.UNET_CASES[name]
+    x, t = cases.make_unet_inputs(name)
+    eng = build_engine(case["cfg"], case["flavour"], sd)
+    y = eng.forward(x.to(dev), t.to(dev)).cpu().numpy()
+    assert maxabs(y, g["y"]) <= FP32_TOL
+
+
+def test_unet_batch_independence_and_determinism(dev):
+    """Size-independent properties at the headline config: images of a batch do not
+    interact (GroupNorm/attention are per-sample) and reruns are bitwise identical."""
+    name = "sr3_128"
+    sd, _ = golden_state_dict("unet_" + name)
+    case = cases.UNET_CASES[name]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((4, 6, 128, 128), generator=g).to(dev)
+    t = (0.1 + 0.9 * torch.rand((4, 1), generator=g)).to(dev)
+    eng = build_engine(case["cfg"], "sr3", sd)
+    y4 = eng.forward(x, t)
+    y4b = eng.forward(x, t)
+    assert torch.equal(y4, y4b)
+    y1 = eng.forward(x[2:3].contiguous(), t[2:3].contiguous())
+    assert maxabs(y1.cpu(), y4[2:3].cpu()) <= 1e-5
+
+
+# ----------------------------------------------------------------------------- sampling loops
+def _sr3_engine_run(eng, sch, cond, draws, dev, use_graph, clip=True, kind="sr3"):
+    from diffsplitting_amd import engine
+    bufs, gam = engine.gaussian_buffers(sch)
+    tab = engine.gaussian_step_table(bufs, gam, kind, clip)
+    T = tab.n_steps
+    x0 = draws[0].to(dev)
+    per_step = draws[1:]
+    noise = torch.zeros((T,) + tuple(x0.shape))
+    for s, d in enumerate(per_step):
+        noise[s] = d
+    snaps = engine.gaussian_snapshot_steps(T)
+    x, sn = eng.sample_loop(tab, x0.clone(), cond=cond.to(dev), noise=noise.to(dev),
+                            snapshot_steps=snaps, use_graph=use_graph)
+    torch.cuda.synchronize()
+    return x.cpu(), sn.cpu()
+
+
+@pytest.mark.parametrize("sched,use_graph", [("lin_8", False), ("lin_8", True), ("lin_25", True)])
+def test_sr3_loop(sched, use_graph, dev):
+    sd, g = golden_state_dict("loop_sr3_" + sched)
+    case = cases.UNET_CASES["sr3_tiny"]
+    sch = cases.SCHEDULES[sched]
+    cond = cases.make_cond("sr3_loop")
+    rec = DrawRecorder(cases.LOOP_SEED)
+    osd = {"denoise_fn." + k: v for k, v in sd.items()}
+    ret, full = samplers.sr3_p_sample_loop(osd, case["cfg"], samplers.gaussian_schedule(sch), cond, randn=rec,
+                                           continous=True, return_full=True)
+    eng = build_engine(case["cfg"], "sr3", sd)
+    x, sn = _sr3_engine_run(eng, sch, cond, rec.draws, dev, use_graph)
+    assert maxabs(x, full) <= FP32_TOL, maxabs(x, full)
+    # continuous stack = [cond | snapshots...] (diffusion.py:195-199)
+    stack = torch.cat([cond] + [s for s in sn], dim=0)
+    assert stack.shape == ret.shape
+    assert maxabs(stack, ret) <= FP32_TOL
+    print(f"\nsr3 {sched} graph={use_graph}: max|hip-oracle| = {maxabs(x, full):.3e}")
+
+
+def test_sr3_loop_seeded_matches_golden(dev):
+    """Same torch seed as the golden run -> the injected draws equal the reference's own."""
+    sd, g = golden_state_dict("loop_sr3_lin_8")
+    case = cases.UNET_CASES["sr3_tiny"]
+    sch = cases.SCHEDULES["lin_8"]
+    cond = cases.make_cond("sr3_loop")
+    torch.manual_seed(cases.LOOP_SEED)
+    draws = [torch.randn(2, 3, 32, 32) for _ in range(8)]  # init + T-1 steps, reference draw order
+    eng = build_engine(case["cfg"], "sr3", sd)
+    x, sn = _sr3_engine_run(eng, sch, cond, draws, dev, True)
+    stack = torch.cat([cond] + [s for s in sn], dim=0).numpy()
+    assert maxabs(stack, g["ret"]) <= FP32_TOL
+    assert maxabs(x[-1].numpy(), g["last"]) <= FP32_TOL  # non-continuous return = last batch element (Q1)
+
+
+def test_ddpm_loop(dev):
+    sd, g = golden_state_dict("loop_ddpm_lin_8")
+    cfg = cases.DDPM_COND_CASE["cfg"]
+    sch = cases.SCHEDULES["lin_8"]
+    cond = cases.make_cond("ddpm_loop")
+    torch.manual_seed(cases.LOOP_SEED)
+    draws = [torch.randn(2, 1, 32, 32) for _ in range(9)]  # init + T draws (drawn even at t == 0)
+    eng = build_engine(cfg, "ddpm", sd)
+    x, sn = _sr3_engine_run(eng, sch, cond, draws, dev, True, kind="ddpm")
+    stack = torch.cat([cond] + [s for s in sn], dim=0).numpy()
+    assert maxabs(stack, g["ret"]) <= FP32_TOL, maxabs(stack, g["ret"])
+
+
+def _indi_engine_run(eng, x_in, n, t0, out_channel, draws, dev, use_graph=True, e=0.01, stream=None):
+    from diffsplitting_amd import engine
+    tab = engine.indi_step_table(n, t0, e)
+    xin = torch.cat([x_in] * out_channel, dim=1)
+    x0 = xin + draws[0] * (e * torch.Tensor([t0]))  # indi.py:80-82
+    noise = torch.stack(draws[1:1 + n])
+    x, sn = eng.sample_loop(tab, x0.to(dev), noise=noise.to(dev), snapshot_steps=engine.indi_snapshot_steps(n),
+                            use_graph=use_graph, stream=stream)
+    return x0, x, sn
+
+
+@pytest.mark.parametrize("n,t0", [(1, 1.0), (3, 1.0), (10, 1.0), (20, 1.0), (4, 0.6)])
+def test_indi_loop(n, t0, dev):
+    sd, g = golden_state_dict(f"loop_indi_n{n}_t{t0}")
+    case = cases.UNET_CASES["ddpm_tiny"]
+    x_in = cases.make_cond("indi_loop")
+    torch.manual_seed(cases.LOOP_SEED)
+    draws = [torch.randn(3, 2, 32, 48) for _ in range(n + 1)]
+    eng = build_engine(case["cfg"], "ddpm", sd)
+    x0, x, sn = _indi_engine_run(eng, x_in, n, t0, 2, draws, dev)
+    torch.cuda.synchronize()
+    stack = torch.cat([x0] + [s for s in sn.cpu()], dim=0).numpy()
+    assert stack.shape == g["ret"].shape
+    assert maxabs(stack, g["ret"]) <= FP32_TOL, maxabs(stack, g["ret"])
+    assert maxabs(x.cpu()[-1:].numpy(), g["last"]) <= FP32_TOL
+
+
+def test_joint_indi_two_streams(dev):
+    """JointIndi (joint_indi.py:131-135): the two InDI loops run concurrently on two HIP streams."""
+    sd, g = golden_state_dict("loop_joint_n3")
+    case = cases.UNET_CASES["joint_32"]
+    x_in = cases.make_cond("joint_loop")
+    torch.manual_seed(cases.LOOP_SEED)
+    d1 = [torch.randn(2, 1, 32, 32) for _ in range(4)]  # all of indi1's draws first (Q4)
+    d2 = [torch.randn(2, 1, 32, 32) for _ in range(4)]
+    e1 = build_engine(case["cfg"], "ddpm", sd, prefix="indi1.denoise_fn.")
+    e2 = build_engine(case["cfg"], "ddpm", sd, prefix="indi2.denoise_fn.")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    a0, a, asn = _indi_engine_run(e1, x_in, 3, 0.5, 1, d1, dev, stream=s1)
+    b0, b, bsn = _indi_engine_run(e2, x_in, 3, 0.5, 1, d2, dev, stream=s2)
+    torch.cuda.synchronize()
+    ch1 = torch.cat([a0] + [s for s in asn.cpu()], dim=0)
+    ch2 = torch.cat([b0] + [s for s in bsn.cpu()], dim=0)
+    stack = torch.cat([ch1, ch2], dim=1).numpy()
+    assert maxabs(stack, g["ret"]) <= FP32_TOL, maxabs(stack, g["ret"])
+
+
+def test_sr3_2000_steps_tiny(dev):
+    """The full 2000-step schedule of sr_sr3_16_128 on the tiny UNet: drift stays under
+    1e-3 with injected noise (re-association noise ~2e-6 over 2000 steps)."""
+    sd, _ = golden_state_dict("loop_sr3_lin_8")
+    case = cases.UNET_CASES["sr3_tiny"]
+    sch = cases.SCHEDULES["sr3_2000"]
+    g = torch.Generator().manual_seed(3)
+    cond = torch.randn((1, 3, 16, 16), generator=g)
+    rec = DrawRecorder(77)
+    osd = {"denoise_fn." + k: v for k, v in sd.items()}
+    _, full = samplers.sr3_p_sample_loop(osd, case["cfg"], samplers.gaussian_schedule(sch), cond, randn=rec,
+                                         return_full=True)
+    eng = build_engine(case["cfg"], "sr3", sd)
+    x, _ = _sr3_engine_run(eng, sch, cond, rec.draws, dev, True)
+    print(f"\n2000 steps: max|hip-oracle| = {maxabs(x, full):.3e}")
+    assert maxabs(x, full) <= FP32_TOL
+
+
+def test_device_rng_statistics(dev):
+    from diffsplitting_amd import engine
+    z = engine.randn((1 << 20,), seed=5).cpu().numpy().astype(np.float64)
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3
+    assert abs(np.mean(z ** 3)) < 2e-2 and abs(np.mean(z ** 4) - 3.0) < 5e-2
+    z2 = engine.randn((1 << 20,), seed=5).cpu().numpy()
+    assert np.array_equal(z.astype(np.float32), z2)              # reproducible
+    z3 = engine.randn((1 << 20,), seed=6).cpu().numpy()
+    assert abs(np.corrcoef(z[:100000], z3[:100000])[0, 1]) < 2e-2  # seeds decorrelate
+
+
+def test_perf_mode_loop_runs_and_is_seeded(dev):
+    """Device-noise mode: same seed -> identical images, different seed -> different."""
+    from diffsplitting_amd import engine
+    sd, _ = golden_state_dict("loop_sr3_lin_8")
+    case = cases.UNET_CASES["sr3_tiny"]
+    bufs, gam = engine.gaussian_buffers(cases.SCHEDULES["lin_25"])
+    tab = engine.gaussian_step_table(bufs, gam, "sr3", True)
+    cond = cases.make_cond("sr3_loop").to(dev)
+    eng = build_engine(case["cfg"], "sr3", sd)
+    outs = []
+    for seed in (1, 1, 2):
+        x0 = engine.randn((2, 3, 32, 32), seed=seed)
+        x, _ = eng.sample_loop(tab, x0, cond=cond, seed=seed)
+        torch.cuda.synchronize()
+        outs.append(x.cpu())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    assert torch.isfinite(outs[0]).all()
+
+
+# ----------------------------------------------------------------------------- time predictor
+def test_time_predictor(dev):
+    from diffsplitting_amd import engine, _lib
+    import ctypes as C
+    sd, g = golden_state_dict("time_predictor")
+    cfg = cases.TIME_PRED_CFG
+    x = cases.make_cond("time_pred")
+    eng = build_engine(cfg, "ddpm", sd, prefix="unet.", with_time_emb=False)
+    ex = eng.executor(3, 32, 32)
+    w = sd["foreground_mask.layer.weight"].contiguous()
+    b = sd["foreground_mask.layer.bias"].contiguous()
+    _lib.check(_lib.lib.dsx_time_predictor_set_mask(ex, C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr())))
+    xd = x.to(dev).contiguous()
+    out = torch.empty(3, device=dev)
+    _lib.check(_lib.lib.dsx_time_predictor_forward(ex, C.c_void_p(xd.data_ptr()), C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    ref = time_predictor_forward(sd, cfg, x).numpy()
+    assert maxabs(out.cpu().numpy(), g["t"]) <= FP32_TOL and maxabs(out.cpu().numpy(), ref) <= FP32_TOL
+
+
+# ----------------------------------------------------------------------------- tiling
+@pytest.mark.parametrize("name,data_shape,grid_shape,patch_shape", cases.TILE_CASES)
+def test_gather_and_stitch(name, data_shape, grid_shape, patch_shape, dev):
+    from diffsplitting_amd.data.tiling import TilePlan
+    plan = TilePlan(data_shape, grid_shape, patch_shape)
+    oplan = tiling.TilePlan(data_shape, grid_shape, patch_shape)
+    n = plan.total
+    rng = np.random.default_rng(1)
+    C = 2
+    if name == "hagen_490":
+        data_shape = (2, 2048, 2048)  # same plan geometry per frame; keep the CPU check quick
+        plan = TilePlan(data_shape, grid_shape, patch_shape)
+        oplan = tiling.TilePlan(data_shape, grid_shape, patch_shape)
+        n = plan.total
+        assert n == 98
+    frames = rng.standard_normal(tuple(data_shape) + (C,)).astype(np.float32)
+    # gather each channel's tiles on the device, compare with the oracle crop
+    tiles = torch.stack([plan.gather(torch.from_numpy(np.ascontiguousarray(frames[..., c])).to(dev))
+                         for c in range(C)], dim=1)          # (n, C, ph, pw)
+    ref_tiles = np.stack([tiling.extract_patch(frames, oplan, i) for i in range(n)])
+    assert np.array_equal(tiles.cpu().numpy(), ref_tiles)
+    out = plan.stitch(tiles)
+    assert np.array_equal(out.cpu().numpy(), tiling.stitch(ref_tiles, oplan))
+    assert np.array_equal(out.cpu().numpy(), frames)          # encode -> decode round trip
+
+
+def test_stitch_known_answer_on_device(dev):
+    """tests/test_tiling_setup.py of the reference, through the HIP gather/stitch (exact)."""
+    from diffsplitting_amd.data.tiling import TilePlan
+    n, H, W, C = 5, 512, 512, 2
+    data = np.arange(n * H * W * C).reshape(n, H, W, C).astype(np.float32)  # < 2^24: exact in fp32
+    plan = TilePlan((n, H, W), (1, 128, 128), (1, 256, 256))
+    assert plan.total == 45
+    tiles = torch.stack([plan.gather(torch.from_numpy(np.ascontiguousarray(data[..., c])).to(dev))
+                         for c in range(C)], dim=1)
+    assert np.array_equal(plan.stitch(tiles).cpu().numpy(), data)
