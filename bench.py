@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sampled images/s of the 2000-step 128x128 SR3
+p_sample_loop (config sr_sr3_16_128: 16->128 SR3 UNet, batch 16 per GPU),
+on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 2000 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one reverse-diffusion step (UNet forward + posterior update) of the
+whole per-GPU batch, replayed from a captured hipGraph with device (Philox)
+noise; the default K=2000 is one complete sampling loop.  Every step costs the
+same, so images/s = N*B / (2000 * ms_per_step).  Inputs (conditioning images,
+initial noise, weights) are resident in HBM before the timed region.
+
+Adds `roofline` (conv-MFMA kernel family, measured live with HIP events around
+each launch of an eager replay) and `cpu_baseline` (the CPU oracle on the host
+cores, a bounded sample) to the JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SAMPLE_STEPS = 2000
+UNET = dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32, channel_mults=(1, 2, 4, 8, 8),
+            attn_res=(16,), res_blocks=2, image_size=128)             # config/sr_sr3_16_128.json
+SCHEDULE = dict(schedule="linear", n_timestep=SAMPLE_STEPS, linear_start=1e-6, linear_end=1e-2)
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}                          # MI355X_MICROARCH.md, dense
+
+
+def random_init_state_dict(names, shapes, seed=0):
+    """Random-init weights of the architecture (no checkpoints exist offline)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for n, s in zip(names, shapes):
+        if n.endswith("inv_freq"):
+            continue
+        if len(s) == 1:
+            sd[n] = (1.0 + 0.2 * torch.randn(s, generator=g)) if n.endswith("weight") else 0.1 * torch.randn(s, generator=g)
+        else:
+            fan_in = int(np.prod(s[1:]))
+            sd[n] = torch.randn(s, generator=g) * (1.0 / fan_in) ** 0.5
+    return sd
+
+
+def cpu_baseline(sd, batch=4, warm=1, timed=3):
+    """The CPU oracle (oracle/, a checked restatement of the reference's p_sample)
+    on this host's cores: a bounded sample of `timed` reverse steps at batch 4,
+    extrapolated to the 2000-step loop (per-step cost is step-independent)."""
+    from oracle import samplers
+    torch.set_grad_enabled(False)
+    sch = samplers.gaussian_schedule(SCHEDULE)
+    osd = {"denoise_fn." + k: v for k, v in sd.items()}
+    g = torch.Generator().manual_seed(1)
+    cond = torch.randn((batch, 3, 128, 128), generator=g)
+    img = torch.randn((batch, 3, 128, 128), generator=g)
+    randn = lambda shape: torch.randn(shape, generator=g)
+    ts = []
+    for k in range(warm + timed):
+        t0 = time.perf_counter()
+        img = samplers.sr3_p_sample(osd, UNET, sch, img, SAMPLE_STEPS - 1 - k, cond, randn)
+        ts.append(time.perf_counter() - t0)
+    step = float(np.mean(ts[warm:]))
+    return {"value": batch / (step * SAMPLE_STEPS), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{timed} timed p_sample steps (after {warm} warm-up) of the torch-fp32 CPU oracle at "
+                      f"batch {batch}, {step:.3f} s/step, extrapolated x{SAMPLE_STEPS}"}
+
+
+def roofline(eng, ex, dtype, iters=3):
+    from diffsplitting_amd._lib import check, lib
+    n = lib.dsx_exec_num_ops(ex)
+    ms = (C.c_float * n)()
+    check(lib.dsx_exec_profile(ex, 1, ms, C.c_void_p(torch.cuda.current_stream().cuda_stream)))  # warm
+    check(lib.dsx_exec_profile(ex, iters, ms, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    desc = C.create_string_buffer(256)
+    kind, fl, by = C.c_int(), C.c_double(), C.c_double()
+    rows = []
+    for i in range(n):
+        check(lib.dsx_exec_op_info(ex, i, desc, 256, C.byref(kind), C.byref(fl), C.byref(by)))
+        rows.append((kind.value, desc.value.decode(), fl.value, by.value, ms[i]))
+    conv = [r for r in rows if r[0] == 0]
+    conv_ms = sum(r[4] for r in conv)
+    conv_fl = sum(r[2] for r in conv)
+    total_ms = sum(r[4] for r in rows)
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[dtype]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dtype)
+        except Exception:
+            traffic = None
+    by_kind = {}
+    for r in rows:
+        by_kind[r[0]] = by_kind.get(r[0], 0.0) + r[4]
+    top = sorted(rows, key=lambda r: -r[4])[:8]
+    print("[bench] eager per-launch profile: total %.3f ms/step over %d launches; conv-MFMA %.3f ms (%.1f%%)"
+          % (total_ms, n, conv_ms, 100 * conv_ms / total_ms), file=sys.stderr)
+    names = {0: "conv_mfma", 1: "conv_naive", 2: "gn_stats", 3: "gn_finalize", 4: "attn_gemm", 5: "softmax"}
+    print("[bench] ms by kernel family: " + ", ".join(f"{names[k]} {v:.3f}" for k, v in sorted(by_kind.items())),
+          file=sys.stderr)
+    for r in top:
+        tf = r[2] / (r[4] * 1e-3) / 1e12 if r[4] > 0 else 0.0
+        print(f"[bench]   {r[4]:8.4f} ms  {tf:8.1f} TF/s  {r[1]}", file=sys.stderr)
+    return {"bound": "mfma", "kernel": "k_conv_mfma (all launches of one UNet forward)",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "launches": len(conv), "avg_launch_ms": conv_ms / max(1, len(conv)),
+            "conv_ms_per_step": conv_ms, "all_kernels_ms_per_step": total_ms}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=SAMPLE_STEPS)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU (BASELINE config: 16)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    torch.set_grad_enabled(False)
+
+    from diffsplitting_amd import engine
+    cfg = engine.make_cfg("sr3", **{k: UNET[k] for k in ("in_channel", "out_channel", "inner_channel",
+                                                         "norm_groups", "channel_mults", "attn_res",
+                                                         "res_blocks", "image_size")})
+    eng = engine.UNetEngine(cfg, "sr3")
+    sd = random_init_state_dict(eng.param_names, eng.param_shapes, seed=0)
+    eng.load_state_dict(sd)
+    eng.finalize(args.dtype)
+
+    B, K, W = args.batch, args.steps, args.warmup
+    bufs, gam = engine.gaussian_buffers(SCHEDULE)
+    full = engine.gaussian_step_table(bufs, gam, "sr3", clip_denoised=True)
+
+    def sub(n):  # the first n reverse steps of the real T=2000 schedule (wraps for n > 2000)
+        idx = np.arange(n) % SAMPLE_STEPS
+        return engine.StepTableHost(full.tcond[idx], c1=full.c1[idx], c2=full.c2[idx], sigma=full.sigma[idx],
+                                    a=full.a[idx], b=full.b[idx], predict_eps=True, clip=True)
+
+    g = torch.Generator().manual_seed(100 + rank)
+    cond = torch.randn((B, 3, 128, 128), generator=g).to(dev)      # stands in for the bicubic-upsampled LR
+    x = engine.randn((B, 3, 128, 128), seed=1000 + rank)
+    use_graph = not args.no_graph
+    if W > 0:
+        eng.sample_loop(sub(W), x, cond=cond, seed=rank, use_graph=use_graph)
+    x = engine.randn((B, 3, 128, 128), seed=2000 + rank)
+    tab = sub(K)
+
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x, _ = eng.sample_loop(tab, x, cond=cond, seed=rank, use_graph=use_graph)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the sampler's only exchange: one all-gather of the finished images (outside the loop)
+        out = torch.empty((world * B, 3, 128, 128), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out, x.contiguous())
+        x = out
+    assert torch.isfinite(x).all(), "sampler produced non-finite pixels"
+
+    ms_per_step = elapsed * 1e3 / K
+    images_per_s = world * B / (ms_per_step * 1e-3 * SAMPLE_STEPS)
+    line = {
+        "metric": "sampled images/sec (2000-step 128x128 SR3)",
+        "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "sr_sr3_16_128: GaussianDiffusion.p_sample_loop, 16->128 SR3 UNet (97.8M params), "
+                               "T=2000 linear schedule; one step = UNet forward + posterior update of the batch",
+                   "batch_per_gpu": B, "global_batch": world * B, "image": "128x128x3", "sample_steps": SAMPLE_STEPS,
+                   "parallelism": f"{world} independent replicas, final RCCL all-gather", "hipgraph": use_graph,
+                   "noise": "device Philox4x32-10", "weights": "random-init, seed 0"},
+    }
+    if rank == 0:
+        gf = eng.flops(128, 128)
+        line["unet_gflop_per_image_step"] = gf / 1e9
+        line["sustained_tflops_per_gpu"] = gf * B / (ms_per_step * 1e-3) / 1e12
+        if not args.no_roofline:
+            line["roofline"] = roofline(eng, eng.executor(B, 128, 128, 3), args.dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd)
+            line["speedup_vs_cpu_baseline"] = images_per_s / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,10 +126,10 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H
 struct UpdateArgs {
   float* x;               // state, NHWC [B][H][W][C]
   const float* net;       // UNet output, NHWC
-  const float* noise;     // nullptr -> Philox; else [n_steps][B][C][H][W] (NCHW, reference draw order)
+  const float* noise;     // nullptr -> Philox; else [steps][B][C][H][W] (NCHW, reference draw order)
   unsigned long long seed;
   const float* tab;       // device table [6][n_steps]: tcond,a,b,c1,c2,sigma
-  int n_steps;
+  int n_steps;            // column stride of `tab` (its capacity)
   const int* step_ctr;
   int predict_eps, clip;
   int B, C, H, W;

@@ -472,9 +472,11 @@ struct StatInfo {          // GroupNorm partial sums of one tensor, produced at 
   bool planned = false;
 };
 
-struct LoopState {   // device-resident, read by k_temb / k_update
-  int step;
-  int pad;
+struct OpInfo {            // what one launch of the plan computes (for profiling / roofline)
+  int kind;                // DSX_OP_*
+  std::string desc;
+  double flops;            // algorithmic 2*MAC
+  double bytes;            // algorithmic HBM bytes: inputs + outputs + weights, each once
 };
 
 }  // namespace
@@ -486,6 +488,7 @@ struct dsx_exec {
   size_t ws_bytes = 0, ws_used = 0;
   bool sizing = true;
   std::vector<std::function<hipError_t(hipStream_t)>> ops;  // the UNet forward
+  std::vector<OpInfo> op_info;                               // parallel to ops
   std::vector<StatInfo> stats;
   // fixed buffers
   Tensor in_cond, in_x, out;   // NHWC
@@ -507,6 +510,20 @@ struct dsx_exec {
   float* tp_w = nullptr; float* tp_b = nullptr; float* tp_mask = nullptr;
   int launches = 0;
 };
+
+static void add_op(dsx_exec* ex, int kind, const std::string& desc, double flops, double bytes,
+                   std::function<hipError_t(hipStream_t)> fn) {
+  ex->ops.push_back(std::move(fn));
+  ex->op_info.push_back(OpInfo{kind, desc, flops, bytes});
+}
+static std::string fmt(const char* f, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof buf, f, ap);
+  va_end(ap);
+  return buf;
+}
 
 static char* ws_alloc(dsx_exec* ex, size_t bytes) {
   size_t off = (ex->ws_used + 255) & ~(size_t)255;
@@ -590,8 +607,17 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
   ex->launches++;
   if (ex->sizing) return DSX_OK;
+  const double npix = (double)a.B * a.Ho * a.Wo;
+  const double cin = a.C0 + a.C1;
+  const double flops = 2.0 * npix * a.Cout * cin * ks * ks;
+  const double wbytes = (double)a.Cout * cin * ks * ks * (dtype == 1 ? 2 : 4);
+  const double bytes = 4.0 * ((double)a.B * a.Hs * a.Ws * cin + npix * a.Cout * (a.resid ? 2 : 1)) + wbytes;
   if (mfma_ok) {
-    ex->ops.push_back([=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
+    const ConvTileInfo ti = conv_tile_info(tile);
+    add_op(ex, DSX_OP_CONV_MFMA,
+           fmt("conv%dx%d%s%s %d->%d @%dx%d tile%dx%d", ks, ks, stride == 2 ? "s2" : "", a.up ? "up" : "",
+               (int)cin, a.Cout, a.Ho, a.Wo, ti.BM, ti.BN),
+           flops, bytes, [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
   } else {
     if (!s.w->naive)
       return fail(DSX_ERR_INVALID,
@@ -599,7 +625,8 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
                   a.Ho, a.Wo, a.B);
     NaiveConvArgs na{};
     na.c = a; na.w = s.w->naive; na.ks = ks; na.stride = stride; na.sigmoid_out = 0;
-    ex->ops.push_back([=](hipStream_t st) { return launch_conv_naive(na, st); });
+    add_op(ex, DSX_OP_CONV_NAIVE, fmt("conv%dx%d-naive %d->%d @%dx%d", ks, ks, (int)cin, a.Cout, a.Ho, a.Wo),
+           flops, bytes, [=](hipStream_t st) { return launch_conv_naive(na, st); });
   }
   return DSX_OK;
 }
@@ -618,7 +645,8 @@ static void plan_stats(dsx_exec* ex, const Tensor& t) {
   if (ex->sizing) return;
   const float* x = t.p; double* part = si.part;
   const int B = ex->B, C = t.C;
-  ex->ops.push_back([=](hipStream_t st) { return launch_chan_stats(x, B, HW, C, nchunk, part, st); });
+  add_op(ex, DSX_OP_GN_STATS, fmt("gn_stats C=%d @%dx%d", C, t.H, t.W), 0.0, 4.0 * B * HW * C,
+         [=](hipStream_t st) { return launch_chan_stats(x, B, HW, C, nchunk, part, st); });
 }
 
 // GroupNorm over cat(t0, t1) -> device scale/shift [B][C]
@@ -637,7 +665,8 @@ static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* 
   a.B = ex->B; a.groups = ex->m->cfg.norm_groups; a.count = (double)t0.H * t0.W;
   a.gamma = g.gamma; a.beta = g.beta; a.eps = 1e-5f;
   a.scale = *scale; a.shift = *shift;
-  ex->ops.push_back([=](hipStream_t st) { return launch_gn_finalize(a, st); });
+  add_op(ex, DSX_OP_GN_FINALIZE, fmt("gn_finalize C=%d", C), 0.0, 0.0,
+         [=](hipStream_t st) { return launch_gn_finalize(a, st); });
 }
 
 static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tensor* x1, Tensor& y) {
@@ -685,14 +714,17 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
     g1.Bm = qkv.p + C; g1.ldb = 3 * C; g1.sB = g1.sA; g1.b_kmajor = 0;
     g1.Cm = S; g1.ldc = L; g1.sC = (long long)L * L;
     g1.M = L; g1.N = L; g1.K = C; g1.batch = B; g1.div = sqrtf((float)C);
-    ex->ops.push_back([=](hipStream_t st) { return launch_bgemm(g1, st); });
-    ex->ops.push_back([=](hipStream_t st) { return launch_softmax_rows(S, (long long)B * L, L, st); });
+    add_op(ex, DSX_OP_ATTN_GEMM, fmt("attn QK^T L=%d d=%d", L, C), 2.0 * B * L * (double)L * C,
+           4.0 * B * (2.0 * L * C + (double)L * L), [=](hipStream_t st) { return launch_bgemm(g1, st); });
+    add_op(ex, DSX_OP_SOFTMAX, fmt("softmax L=%d", L), 0.0, 8.0 * B * (double)L * L,
+           [=](hipStream_t st) { return launch_softmax_rows(S, (long long)B * L, L, st); });
     BgemmArgs g2{};
     g2.A = S; g2.lda = L; g2.sA = (long long)L * L;
     g2.Bm = qkv.p + 2 * C; g2.ldb = 3 * C; g2.sB = (long long)L * 3 * C; g2.b_kmajor = 1;
     g2.Cm = av.p; g2.ldc = C; g2.sC = (long long)L * C;
     g2.M = L; g2.N = C; g2.K = L; g2.batch = B; g2.div = 1.0f;
-    ex->ops.push_back([=](hipStream_t st) { return launch_bgemm(g2, st); });
+    add_op(ex, DSX_OP_ATTN_GEMM, fmt("attn PV L=%d d=%d", L, C), 2.0 * B * L * (double)L * C,
+           4.0 * B * (2.0 * L * C + (double)L * L), [=](hipStream_t st) { return launch_bgemm(g2, st); });
   }
   Tensor o2 = new_tensor(ex, C, H, W);
   ConvSpec co{};
@@ -706,6 +738,7 @@ static int build_plan(dsx_exec* ex) {
   dsx_model* m = ex->m;
   ex->ws_used = 0;
   ex->ops.clear();
+  ex->op_info.clear();
   ex->stats.clear();
   ex->launches = 0;
   const int B = ex->B;
@@ -805,6 +838,44 @@ extern "C" void dsx_exec_destroy(dsx_exec* ex) {
 extern "C" size_t dsx_exec_workspace_bytes(const dsx_exec* ex) { return ex ? ex->ws_bytes : 0; }
 extern "C" int dsx_exec_num_launches(const dsx_exec* ex) { return ex ? ex->launches : 0; }
 
+extern "C" int dsx_exec_num_ops(const dsx_exec* ex) { return ex ? (int)ex->ops.size() : 0; }
+extern "C" int dsx_exec_op_info(const dsx_exec* ex, int i, char* desc, int cap, int* kind, double* flops,
+                                double* bytes) {
+  if (!ex || i < 0 || i >= (int)ex->op_info.size()) return fail(DSX_ERR_INVALID, "bad op index");
+  const OpInfo& o = ex->op_info[i];
+  if (desc && cap > 0) snprintf(desc, cap, "%s", o.desc.c_str());
+  if (kind) *kind = o.kind;
+  if (flops) *flops = o.flops;
+  if (bytes) *bytes = o.bytes;
+  return DSX_OK;
+}
+// Eager, event-timed replay of the UNet plan on `stream` (inputs: whatever the
+// buffers hold).  ms_per_op[i] = mean over `iters` of the hipEvent time around launch i.
+extern "C" int dsx_exec_profile(dsx_exec* ex, int iters, float* ms_per_op, void* stream) {
+  if (!ex || !ms_per_op || iters < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = ex->ops.size();
+  std::vector<hipEvent_t> ev(2 * n);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  std::vector<double> acc(n, 0.0);
+  for (int it = 0; it < iters; ++it) {
+    for (size_t i = 0; i < n; ++i) {
+      HIP_TRY(hipEventRecord(ev[2 * i], st));
+      HIP_TRY(ex->ops[i](st));
+      HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; ++i) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+      acc[i] += ms;
+    }
+  }
+  for (size_t i = 0; i < n; ++i) ms_per_op[i] = (float)(acc[i] / iters);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return DSX_OK;
+}
+
 // time embedding + UNet body on `st`; inputs already in ex->in_cond / ex->in_x
 static int run_unet(dsx_exec* ex, bool from_table, int n_time, hipStream_t st) {
   dsx_model* m = ex->m;
@@ -858,17 +929,20 @@ static int load_inputs(dsx_exec* ex, const float* cond_nchw, const float* x_nchw
 static int ensure_table(dsx_exec* ex, const dsx_step_table* tab) {
   const int T = tab->n_steps;
   if (T > ex->table_cap) {
+    // the table's column stride (= capacity) is baked into captured graphs: drop them
     if (ex->graph_exec) { (void)hipGraphExecDestroy(ex->graph_exec); ex->graph_exec = nullptr; }
     if (ex->graph) { (void)hipGraphDestroy(ex->graph); ex->graph = nullptr; }
     if (ex->table) (void)hipFree(ex->table);
     ex->table = nullptr;
-    HIP_TRY(hipMalloc((void**)&ex->table, (size_t)6 * T * sizeof(float)));
-    ex->table_cap = T;
+    const int cap = std::max(T, 2048);
+    HIP_TRY(hipMalloc((void**)&ex->table, (size_t)6 * cap * sizeof(float)));
+    ex->table_cap = cap;
   }
-  ex->table_host.assign((size_t)6 * T, 0.f);
+  const int cap = ex->table_cap;
+  ex->table_host.assign((size_t)6 * cap, 0.f);
   const float* cols[6] = {tab->tcond, tab->a, tab->b, tab->c1, tab->c2, tab->sigma};
   for (int k = 0; k < 6; ++k)
-    if (cols[k]) memcpy(ex->table_host.data() + (size_t)k * T, cols[k], (size_t)T * 4);
+    if (cols[k]) memcpy(ex->table_host.data() + (size_t)k * cap, cols[k], (size_t)T * 4);
   return DSX_OK;
 }
 
@@ -878,7 +952,7 @@ static int enqueue_step(dsx_exec* ex, const dsx_step_table* tab, const float* no
   if (rc) return rc;
   UpdateArgs u{};
   u.x = ex->in_x.p; u.net = ex->out.p; u.noise = noise; u.seed = seed;
-  u.tab = ex->table; u.n_steps = tab->n_steps; u.step_ctr = ex->step_ctr;
+  u.tab = ex->table; u.n_steps = ex->table_cap; u.step_ctr = ex->step_ctr;
   u.predict_eps = tab->predict_eps; u.clip = tab->clip;
   u.B = ex->B; u.C = ex->x_c; u.H = ex->H; u.W = ex->W;
   HIP_TRY(launch_update(u, st));
@@ -899,15 +973,16 @@ extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const fl
   const int T = tab->n_steps;
   int rc = ensure_table(ex, tab);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(ex->table, ex->table_host.data(), (size_t)6 * T * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ex->table, ex->table_host.data(), (size_t)6 * ex->table_cap * 4,
+                         hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(ex->step_ctr, 0, 4, st));
   if ((rc = load_inputs(ex, cond, x, ex->x_c, 0, st))) return rc;
 
   const size_t snap_elems = (size_t)ex->B * ex->x_c * ex->H * ex->W;
   bool graph_ok = false;
   if (use_graph) {
-    // the captured step bakes in: n_steps (table stride), mode flags, noise pointer, seed
-    std::vector<float> sig = {(float)T, (float)tab->predict_eps, (float)tab->clip};
+    // the captured step bakes in: mode flags, noise pointer, seed (not the step count)
+    std::vector<float> sig = {(float)tab->predict_eps, (float)tab->clip};
     uint64_t np = (uint64_t)(uintptr_t)noise;
     float f[4];
     memcpy(f, &np, 8); memcpy(f + 2, &seed, 8);

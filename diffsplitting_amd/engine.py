@@ -179,6 +179,13 @@ class UNetEngine:
         steps = np.asarray(sorted(int(s) for s in snapshot_steps), dtype=np.int32)
         if len(steps):
             snaps = torch.empty((len(steps), B, Cx, H, W), dtype=torch.float32, device=x.device)
+        if stream is not None:
+            # the loop runs asynchronously on `stream`: tell torch's caching allocator, or a
+            # tensor dropped by the caller is recycled while the kernels still read it
+            stream.wait_stream(torch.cuda.current_stream())
+            for t in (x, cond, noise, snaps):
+                if t is not None:
+                    t.record_stream(stream)
         sp = C.c_void_p(stream.cuda_stream) if stream is not None else _stream_ptr()
         check(lib.dsx_sample_loop(ex, C.byref(table.c_struct()), _dptr(cond), _dptr(x), _dptr(noise),
                                   C.c_uint64(int(seed) & (2 ** 64 - 1)),

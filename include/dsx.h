@@ -102,6 +102,15 @@ void dsx_exec_destroy(dsx_exec* ex);
 size_t dsx_exec_workspace_bytes(const dsx_exec* ex);
 int dsx_exec_num_launches(const dsx_exec* ex);
 
+/* Launch-level introspection for measurement (bench.py roofline): the plan's
+ * launches in order, what each computes, and an eager hipEvent-timed replay. */
+enum { DSX_OP_CONV_MFMA = 0, DSX_OP_CONV_NAIVE = 1, DSX_OP_GN_STATS = 2, DSX_OP_GN_FINALIZE = 3,
+       DSX_OP_ATTN_GEMM = 4, DSX_OP_SOFTMAX = 5 };
+int dsx_exec_num_ops(const dsx_exec* ex);
+int dsx_exec_op_info(const dsx_exec* ex, int index, char* desc_buf, int desc_cap, int* kind,
+                     double* flops, double* bytes);
+int dsx_exec_profile(dsx_exec* ex, int iters, float* ms_per_op, void* stream);
+
 /* One UNet forward: replaces denoise_fn(x, t)
  * (sr3 unet.py:235-259 / ddpm unet.py:220-243).
  *   x_nchw_dev : (B, in_channel, H, W) fp32, NCHW as the reference passes it
