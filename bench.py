@@ -58,6 +58,7 @@ def cpu_baseline(sd, batch=4, warm=1, timed=3):
     extrapolated to the 2000-step loop (per-step cost is step-independent)."""
     from oracle import samplers
     torch.set_grad_enabled(False)
+    torch.set_num_threads(host_threads())
     sch = samplers.gaussian_schedule(SCHEDULE)
     osd = {"denoise_fn." + k: v for k, v in sd.items()}
     g = torch.Generator().manual_seed(1)
@@ -74,6 +75,22 @@ def cpu_baseline(sd, batch=4, warm=1, timed=3):
             "kind": "port",
             "sample": f"{timed} timed p_sample steps (after {warm} warm-up) of the torch-fp32 CPU oracle at "
                       f"batch {batch}, {step:.3f} s/step, extrapolated x{SAMPLE_STEPS}"}
+
+
+def names_of(k):
+    return {0: "conv_mfma", 1: "conv_naive", 2: "gn_stats", 3: "gn_finalize", 4: "attn_gemm", 5: "softmax"}[k]
+
+
+def host_threads():
+    """CPU threads this process may really use (cgroup quota / affinity), not the host's core count."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def roofline(eng, ex, dtype, iters=3):
@@ -104,6 +121,11 @@ def roofline(eng, ex, dtype, iters=3):
     by_kind = {}
     for r in rows:
         by_kind[r[0]] = by_kind.get(r[0], 0.0) + r[4]
+    dump = os.environ.get("DSX_BENCH_OPS")
+    if dump:
+        with open(dump, "w") as f:
+            json.dump([{"kind": names_of(r[0]), "desc": r[1], "gflop": r[2] / 1e9, "mbytes": r[3] / 1e6,
+                        "ms": r[4]} for r in rows], f, indent=0)
     top = sorted(rows, key=lambda r: -r[4])[:8]
     print("[bench] eager per-launch profile: total %.3f ms/step over %d launches; conv-MFMA %.3f ms (%.1f%%)"
           % (total_ms, n, conv_ms, 100 * conv_ms / total_ms), file=sys.stderr)
