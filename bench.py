@@ -78,7 +78,8 @@ def cpu_baseline(sd, batch=4, warm=1, timed=3):
 
 
 def names_of(k):
-    return {0: "conv_mfma", 1: "conv_naive", 2: "gn_stats", 3: "gn_finalize", 4: "attn_gemm", 5: "softmax"}[k]
+    return {0: "conv_mfma", 1: "conv_naive", 2: "gn_stats", 3: "gn_finalize", 4: "attn_gemm", 5: "softmax",
+            6: "splitk_reduce"}[k]
 
 
 def host_threads():
@@ -129,8 +130,7 @@ def roofline(eng, ex, dtype, iters=3):
     top = sorted(rows, key=lambda r: -r[4])[:8]
     print("[bench] eager per-launch profile: total %.3f ms/step over %d launches; conv-MFMA %.3f ms (%.1f%%)"
           % (total_ms, n, conv_ms, 100 * conv_ms / total_ms), file=sys.stderr)
-    names = {0: "conv_mfma", 1: "conv_naive", 2: "gn_stats", 3: "gn_finalize", 4: "attn_gemm", 5: "softmax"}
-    print("[bench] ms by kernel family: " + ", ".join(f"{names[k]} {v:.3f}" for k, v in sorted(by_kind.items())),
+    print("[bench] ms by kernel family: " + ", ".join(f"{names_of(k)} {v:.3f}" for k, v in sorted(by_kind.items())),
           file=sys.stderr)
     for r in top:
         tf = r[2] / (r[4] * 1e-3) / 1e12 if r[4] > 0 else 0.0

@@ -30,7 +30,6 @@ namespace dsx {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-static constexpr int PIXB = 80;  // LDS bytes per patch pixel: 64 B payload + 16 B pad
 
 __device__ __forceinline__ float swish_f(float v) {
   return __fdividef(v, 1.0f + __expf(-v));
@@ -47,16 +46,24 @@ template <typename DT> struct Chunk;
 template <> struct Chunk<float> { static constexpr int KC = 16; };
 template <> struct Chunk<__bf16> { static constexpr int KC = 32; };
 
-template <typename DT, int MB, int NB, int WM, int WN, int KS, int S, int MAX_IT>
+// MB   : 32-row M blocks per wave;  WM x WN waves (WM*WN == 4); every wave owns ONE
+//        32-channel N block, so with WM == 1 no weight fragment is loaded twice.
+// CPG  : channel chunks staged per barrier ("group"); 1 for 3x3, 2 for 1x1 (few steps per chunk)
+// D    : depth of the weight-fragment prefetch ring (global -> VGPR), steps ahead
+template <typename DT, int MB, int WM, int WN, int KS, int S, int CPG, int D, int MAX_IT>
 __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   constexpr int KC = Chunk<DT>::KC;
-  constexpr int UPP = KC / 4;        // 4-channel staging units per pixel per chunk
-  constexpr int UPP_LOG2 = (UPP == 8) ? 3 : 2;
-  constexpr int UB = 4 * (int)sizeof(DT);  // LDS bytes per staging unit
+  constexpr int UPP = KC / 4;                 // 4-channel staging units per pixel per chunk
+  constexpr int UPG = UPP * CPG;              // ... per group
+  constexpr int UPG_LOG2 = UPG == 16 ? 4 : (UPG == 8 ? 3 : 2);
+  constexpr int UB = 4 * (int)sizeof(DT);     // LDS bytes per staging unit
+  constexpr int PIXB = 64 * CPG + 16;         // LDS bytes per patch pixel (odd multiple of 16: conflict-free b128 reads)
   constexpr int TAPS = KS * KS;
   constexpr int PAD = KS / 2;
-  constexpr int NSTEP = TAPS * 2;    // (tap, 32-B half-chunk) MFMA steps per chunk
+  constexpr int NSTEP = CPG * TAPS * 2;       // MFMA steps per group: (chunk, tap, 32-B half)
   constexpr bool IS_BF16 = sizeof(DT) == 2;
+  static_assert(NSTEP % D == 0, "ring depth must divide the steps per group");
+  static_assert(WM * WN == 4, "4 waves");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -72,10 +79,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   const int PPI = PH * PW;                       // patch pixels per image
   const int PP = PPI << a.tb_log2;               // patch pixels per tile
   const int BUFB = (PP * PIXB + 15) & ~15;
+  const bool multi_img = a.tb_log2 != 0;
 
-  // ---- tile coordinates
+  // ---- tile coordinates: blockIdx.x = (split * n_tiles + nt) * m_tiles + mt
   const int mt = blockIdx.x % a.m_tiles;
-  const int nt = blockIdx.x / a.m_tiles;
+  const int rest = blockIdx.x / a.m_tiles;
+  const int nt = rest % a.n_tiles;
+  const int split = rest / a.n_tiles;
   const int txi = mt % a.tiles_x;
   const int tyi = (mt / a.tiles_x) % a.tiles_y;
   const int bg = mt / (a.tiles_x * a.tiles_y);
@@ -84,15 +94,18 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   const int Hi = a.up ? a.Hs * 2 : a.Hs;
   const int Wi = a.up ? a.Ws * 2 : a.Ws;
   const int C = a.C0 + a.C1;
+  const int kgroups = a.kchunks / CPG;
+  const int g0 = split * a.groups_per_split;
+  const int g1 = min(kgroups, g0 + a.groups_per_split);
 
   // ---- staging plan: which source pixel feeds each of this thread's units
-  const int nunits = PP << UPP_LOG2;
+  const int nunits = PP << UPG_LOG2;
   int soff[MAX_IT];   // source pixel index, or -1 (zero padding / outside batch)
-  int simg[MAX_IT];   // image index (for the GroupNorm scale/shift lookup)
+  int simg[MAX_IT];   // image index (GroupNorm scale/shift lookup when a tile spans images)
 #pragma unroll
   for (int it = 0; it < MAX_IT; ++it) {
     const int u = tid + it * 256;
-    const int pix = u >> UPP_LOG2;
+    const int pix = u >> UPG_LOG2;
     int so = -1, b = b0;
     if (u < nunits) {
       const int tb = pix / PPI;
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
     soff[it] = so;
     simg[it] = b;
   }
-  const int cv = tid & (UPP - 1);  // this thread's 4-channel group inside a chunk (same for all its units)
+  const int cvg = tid & (UPG - 1);  // this thread's 4-channel unit inside a group (same for all its units)
 
   // ---- A-fragment LDS base offsets for this wave's MB row blocks
   int abase[MB];
@@ -123,28 +136,27 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
     abase[mb] = ((tb * PH + ty * S) * PW + tx * S) * PIXB + lh * 16;
   }
 
-  // ---- B-fragment global pointers (fragment-packed weights), 16 B per lane per step
-  const uint4* wp[NB];
+  // ---- B fragments: fragment-packed weights, one coalesced 16-B load per lane per step,
+  //      kept D steps ahead in a register ring (the step index runs on across groups)
+  int blk = nt * WN + wn;
+  if (blk >= a.nblocks) blk = a.nblocks - 1;  // results of a clamped block are never stored
+  const uint4* wpb = (const uint4*)a.wpack + (size_t)blk * kgroups * (NSTEP * 64) + lane;
+  const int q_end = g1 * NSTEP;               // one past this workgroup's last step
+  uint4 bq[D];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    int blk = nt * (NB * WN) + wn * NB + nb;
-    if (blk >= a.nblocks) blk = a.nblocks - 1;  // results of a clamped block are never stored
-    wp[nb] = (const uint4*)a.wpack + (size_t)blk * a.kchunks * (NSTEP * 64) + lane;
-  }
+  for (int j = 0; j < D; ++j) bq[j] = wpb[(size_t)min(g0 * NSTEP + j, q_end - 1) * 64];
 
-  f32x16 acc[MB][NB];
+  f32x16 acc[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
 
   float4 stg[MAX_IT];
 
-  // issue the global loads of chunk kc into registers
-  auto stage_load = [&](int kc) {
-    const int c = kc * KC + cv * 4;
+  // issue the global loads of group g into registers
+  auto stage_load = [&](int g) {
+    const int c = g * (CPG * KC) + cvg * 4;
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -170,30 +182,35 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   };
 
   // GroupNorm affine + Swish in registers, convert, park in LDS buffer `buf`
-  auto stage_store = [&](int kc, int buf) {
-    const int c = kc * KC + cv * 4;
+  auto stage_store = [&](int g, int buf) {
+    const int c = g * (CPG * KC) + cvg * 4;
     unsigned char* dst = lds + buf * BUFB;
+    const bool has_gn = a.gn_scale != nullptr && c < C;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_affine = [&](int b) {
+      const size_t gi = (size_t)b * C + c;
+      if (!a.scalar_stage) {
+        const float4 s4 = *(const float4*)(a.gn_scale + gi);
+        const float4 h4 = *(const float4*)(a.gn_shift + gi);
+        sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+        sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sc[j] = (c + j < C) ? a.gn_scale[gi + j] : 0.f;
+          sh[j] = (c + j < C) ? a.gn_shift[gi + j] : 0.f;
+        }
+      }
+    };
+    if (has_gn && !multi_img) load_affine(b0);  // one image per tile: same (b, c) for every unit
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
       const int u = tid + it * 256;
       if (u < nunits) {
         float4 v = stg[it];
         if (soff[it] >= 0 && c < C) {
-          if (a.gn_scale) {
-            const size_t gi = (size_t)simg[it] * C + c;
-            float sc[4], sh[4];
-            if (!a.scalar_stage) {
-              const float4 s4 = *(const float4*)(a.gn_scale + gi);
-              const float4 h4 = *(const float4*)(a.gn_shift + gi);
-              sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
-              sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                sc[j] = (c + j < C) ? a.gn_scale[gi + j] : 0.f;
-                sh[j] = (c + j < C) ? a.gn_shift[gi + j] : 0.f;
-              }
-            }
+          if (has_gn) {
+            if (multi_img) load_affine(simg[it]);
             v.x = v.x * sc[0] + sh[0];
             v.y = v.y * sc[1] + sh[1];
             v.z = v.z * sc[2] + sh[2];
@@ -208,8 +225,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
             if (c + 3 >= C) v.w = 0.f;
           }
         }
-        const int pix = u >> UPP_LOG2;
-        unsigned char* p = dst + pix * PIXB + cv * UB;
+        const int pix = u >> UPG_LOG2;
+        unsigned char* p = dst + pix * PIXB + cvg * UB;
         if constexpr (IS_BF16) {
           uint2 w;
           w.x = pack_bf16x2(v.x, v.y);
@@ -222,108 +239,101 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
     }
   };
 
-  // ---- main loop over input-channel chunks (double-buffered LDS, one barrier per chunk)
-  stage_load(0);
-  stage_store(0, 0);
+  // ---- main loop over channel groups (double-buffered LDS, one barrier per group)
+  stage_load(g0);
+  stage_store(g0, 0);
   __syncthreads();
 
-  for (int kc = 0; kc < a.kchunks; ++kc) {
-    const bool more = (kc + 1) < a.kchunks;
-    const unsigned char* abuf = lds + (kc & 1) * BUFB;
+  for (int g = g0; g < g1; ++g) {
+    const bool more = (g + 1) < g1;
+    const unsigned char* abuf = lds + ((g - g0) & 1) * BUFB;
+    const int qbase = g * NSTEP;
 
-    uint4 bcur[NB], bnxt[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bcur[nb] = wp[nb][(size_t)kc * (NSTEP * 64)];
-
-    if (more) stage_load(kc + 1);
+    if (more) stage_load(g + 1);
 
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-      if (s + 1 < NSTEP) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bnxt[nb] = wp[nb][(size_t)kc * (NSTEP * 64) + (s + 1) * 64];
-      }
-      const int tap = s >> 1, fs = s & 1;
+      const uint4 bcur = bq[s % D];
+      bq[s % D] = wpb[(size_t)min(qbase + s + D, q_end - 1) * 64];
+      const int cg = s / (TAPS * 2), tap = (s >> 1) % TAPS, fs = s & 1;
       const int dy = tap / KS, dx = tap % KS;
-      const int aoff = (dy * PW + dx) * PIXB + fs * 32;
-      uint4 av[MB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) av[mb] = *(const uint4*)(abuf + abase[mb] + aoff);
+      const int aoff = (dy * PW + dx) * PIXB + cg * 64 + fs * 32;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          if constexpr (IS_BF16) {
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, av[mb]), __builtin_bit_cast(bf16x8, bcur[nb]),
-                acc[mb][nb], 0, 0, 0);
-          } else {
-            const float4 af = __builtin_bit_cast(float4, av[mb]);
-            const float4 bf = __builtin_bit_cast(float4, bcur[nb]);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[mb][nb], 0, 0, 0);
-          }
+        const uint4 av = *(const uint4*)(abuf + abase[mb] + aoff);
+        if constexpr (IS_BF16) {
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                            __builtin_bit_cast(bf16x8, bcur), acc[mb], 0, 0, 0);
+        } else {
+          const float4 af = __builtin_bit_cast(float4, av);
+          const float4 bf = __builtin_bit_cast(float4, bcur);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[mb], 0, 0, 0);
         }
-      }
-      if (s + 1 < NSTEP) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bcur[nb] = bnxt[nb];
       }
     }
 
-    if (more) stage_store(kc + 1, (kc + 1) & 1);
+    if (more) stage_store(g + 1, (g + 1 - g0) & 1);
     __syncthreads();
   }
 
-  // ---- epilogue: + bias + FiLM + residual, NHWC stores
+  // ---- epilogue: NHWC stores; split-K slices write raw partial sums to their slab
+  const int n = (nt * WN + wn) * 32 + li;
+  if (n >= a.Cout) return;
+  const bool partial = a.ksplit > 1;
+  float* outp = a.out + (partial ? (size_t)split * a.slab_stride : 0);
+  const float bias = (!partial && a.bias) ? a.bias[n] : 0.f;
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = (nt * (NB * WN) + wn * NB + nb) * 32 + li;
-    if (n >= a.Cout) continue;
-    const float bias = a.bias ? a.bias[n] : 0.f;
+  for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = (wm * MB + mb) * 32 + row;
-        const int tx = m & (TW - 1);
-        const int ty = (m >> a.tw_log2) & (TH - 1);
-        const int b = b0 + (m >> (a.tw_log2 + a.th_log2));
-        if (b < a.B) {
-          const size_t opix = ((size_t)b * a.Ho + (oy0 + ty)) * a.Wo + (ox0 + tx);
-          float v = acc[mb][nb][r] + bias;
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = (wm * MB + mb) * 32 + row;
+      const int tx = m & (TW - 1);
+      const int ty = (m >> a.tw_log2) & (TH - 1);
+      const int b = b0 + (m >> (a.tw_log2 + a.th_log2));
+      if (b < a.B) {
+        const size_t opix = ((size_t)b * a.Ho + (oy0 + ty)) * a.Wo + (ox0 + tx);
+        float v = acc[mb][r] + bias;
+        if (!partial) {
           if (a.film) v += a.film[(size_t)b * a.film_bs + n];
           if (a.resid) v += a.resid[opix * a.resid_ld + n];
-          a.out[opix * a.out_ld + n] = v;
         }
+        outp[opix * a.out_ld + n] = v;
       }
     }
   }
 }
 
 // ------------------------------------------------------------------ dispatch
-struct TileCfg { int MB, NB, WM, WN; };
+struct TileCfg { int MB, WM, WN; };
 static constexpr TileCfg kTiles[TILE_COUNT] = {
-    {4, 2, 2, 2},  // 256 x 128
-    {4, 1, 2, 2},  // 256 x 64
-    {2, 1, 2, 2},  // 128 x 64
-    {1, 1, 2, 2},  // 64 x 64
+    {8, 1, 4},  // 256 x 128
+    {4, 1, 4},  // 128 x 128
+    {2, 1, 4},  // 64 x 128
+    {4, 2, 2},  // 256 x 64
+    {2, 2, 2},  // 128 x 64
+    {1, 2, 2},  // 64 x 64
 };
 
 ConvTileInfo conv_tile_info(int tile) {
   const TileCfg& t = kTiles[tile];
-  return ConvTileInfo{32 * t.MB * t.WM, 32 * t.NB * t.WN};
+  return ConvTileInfo{32 * t.MB * t.WM, 32 * t.WN};
 }
 
-// staging-register budget (float4 per thread) per (dtype, tile, stride)
-static constexpr int max_it(int dtype, int tile, int stride) {
-  // BM=256: patches up to 400 px (TB=4 of 8x8); 128: 2x100; 64: 1x100 / stride-2 17x17=289
-  const int px = (tile <= TILE_256x64) ? 400 : (tile == TILE_128x64 ? 220 : (stride == 2 ? 400 : 144));
-  const int upp = dtype == 1 ? 8 : 4;
-  return (px * upp + 255) / 256;
+static constexpr int conv_cpg(int ks) { return ks == 1 ? 2 : 1; }
+
+// patch-pixel budget of a tile's staging registers
+static constexpr int max_px(int tile, int ks, int stride) {
+  const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
+  if (ks == 1) return bm;  // no halo
+  return stride == 2 ? 400 : (bm == 256 ? 400 : (bm == 128 ? 220 : 144));
+}
+static constexpr int max_it(int dtype, int tile, int ks, int stride) {
+  const int upg = (dtype == 1 ? 8 : 4) * conv_cpg(ks);
+  return (max_px(tile, ks, stride) * upg + 255) / 256;
 }
 
 static int patch_pixels(int ks, int stride, const ConvArgs& a) {
@@ -331,29 +341,33 @@ static int patch_pixels(int ks, int stride, const ConvArgs& a) {
   return (((TH - 1) * stride + ks) * ((TW - 1) * stride + ks)) << a.tb_log2;
 }
 
+int conv_chunk_multiple(int ks) { return conv_cpg(ks); }
+
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a) {
   if (tile < 0 || tile >= TILE_COUNT) return 0;
   if (!(ks == 1 || ks == 3) || !(stride == 1 || (stride == 2 && ks == 3 && tile == TILE_64x64))) return 0;
   const ConvTileInfo ti = conv_tile_info(tile);
   if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != ti.BM) return 0;
   const int pp = patch_pixels(ks, stride, a);
-  const int upp = dtype == 1 ? 8 : 4;
-  if (pp * upp > max_it(dtype, tile, stride) * 256) return 0;
-  const size_t bufb = ((size_t)pp * PIXB + 15) & ~(size_t)15;
+  if (pp > max_px(tile, ks, stride)) return 0;
+  const size_t pixb = 64 * conv_cpg(ks) + 16;
+  const size_t bufb = ((size_t)pp * pixb + 15) & ~(size_t)15;
+  if (2 * bufb > 64 * 1024) return 0;
   return 2 * bufb;
 }
 
-// a == nullptr: only set the kernel's dynamic-LDS attribute (conv_init)
+// ap == nullptr: only set the kernel's dynamic-LDS attribute (conv_init)
 template <typename DT, int TILE, int KS, int S>
 static hipError_t launch_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
   constexpr TileCfg t = kTiles[TILE];
-  constexpr int MI = max_it(sizeof(DT) == 2 ? 1 : 0, TILE, S);
-  auto kern = k_conv_mfma<DT, t.MB, t.NB, t.WM, t.WN, KS, S, MI>;
+  constexpr int CPG = conv_cpg(KS);
+  constexpr int D = KS == 1 ? 4 : 6;
+  constexpr int MI = max_it(sizeof(DT) == 2 ? 1 : 0, TILE, KS, S);
+  auto kern = k_conv_mfma<DT, t.MB, t.WM, t.WN, KS, S, CPG, D, MI>;
   if (!ap)
-    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   const ConvArgs& a = *ap;
-  const int n_tiles = (a.nblocks + t.NB * t.WN - 1) / (t.NB * t.WN);
-  dim3 grid((unsigned)(a.m_tiles * n_tiles));
+  dim3 grid((unsigned)(a.m_tiles * a.n_tiles * a.ksplit));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   return hipGetLastError();
 }
@@ -361,25 +375,22 @@ static hipError_t launch_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
 template <typename DT>
 static hipError_t launch_dt(int tile, int ks, int stride, const ConvArgs* a, size_t lds, hipStream_t st) {
   if (stride == 2) return launch_one<DT, TILE_64x64, 3, 2>(a, lds, st);
-  if (ks == 3) {
-    switch (tile) {
-      case TILE_256x128: return launch_one<DT, TILE_256x128, 3, 1>(a, lds, st);
-      case TILE_256x64: return launch_one<DT, TILE_256x64, 3, 1>(a, lds, st);
-      case TILE_128x64: return launch_one<DT, TILE_128x64, 3, 1>(a, lds, st);
-      default: return launch_one<DT, TILE_64x64, 3, 1>(a, lds, st);
-    }
-  }
+#define DSX_TILE_CASE(T) \
+  case T: return ks == 3 ? launch_one<DT, T, 3, 1>(a, lds, st) : launch_one<DT, T, 1, 1>(a, lds, st);
   switch (tile) {
-    case TILE_256x128: return launch_one<DT, TILE_256x128, 1, 1>(a, lds, st);
-    case TILE_256x64: return launch_one<DT, TILE_256x64, 1, 1>(a, lds, st);
-    case TILE_128x64: return launch_one<DT, TILE_128x64, 1, 1>(a, lds, st);
-    default: return launch_one<DT, TILE_64x64, 1, 1>(a, lds, st);
+    DSX_TILE_CASE(TILE_256x128)
+    DSX_TILE_CASE(TILE_128x128)
+    DSX_TILE_CASE(TILE_64x128)
+    DSX_TILE_CASE(TILE_256x64)
+    DSX_TILE_CASE(TILE_128x64)
+    default: return ks == 3 ? launch_one<DT, TILE_64x64, 3, 1>(a, lds, st) : launch_one<DT, TILE_64x64, 1, 1>(a, lds, st);
   }
+#undef DSX_TILE_CASE
 }
 
 hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& a, hipStream_t st) {
   const size_t lds = conv_lds_bytes(dtype, tile, ks, stride, a);
-  if (lds == 0) return hipErrorInvalidValue;
+  if (lds == 0 || a.ksplit < 1 || a.n_tiles < 1) return hipErrorInvalidValue;
   return dtype == 1 ? launch_dt<__bf16>(tile, ks, stride, &a, lds, st)
                     : launch_dt<float>(tile, ks, stride, &a, lds, st);
 }

@@ -34,15 +34,20 @@ struct ConvArgs {
   int out_ld;
   int Cout;
   int nblocks;            // ceil(Cout/32)
-  int kchunks;            // ceil((C0+C1)/KC)
+  int kchunks;            // ceil((C0+C1)/KC), padded to conv_chunk_multiple(ks)
   int tw_log2, th_log2, tb_log2;  // output tile = TB images x TH x TW pixels
-  int tiles_x, tiles_y, m_tiles;
+  int tiles_x, tiles_y, m_tiles, n_tiles;
+  int ksplit;             // split-K slices (1 = none); slice s writes raw sums to out + s*slab_stride
+  int groups_per_split;   // channel groups per slice
+  long long slab_stride;  // elements between slabs
 };
 
 // tile configurations compiled for the MFMA conv kernel
-enum ConvTile { TILE_256x128 = 0, TILE_256x64, TILE_128x64, TILE_64x64, TILE_COUNT };
+enum ConvTile { TILE_256x128 = 0, TILE_128x128, TILE_64x128, TILE_256x64, TILE_128x64, TILE_64x64, TILE_COUNT };
 struct ConvTileInfo { int BM, BN; };
 ConvTileInfo conv_tile_info(int tile);
+// input-channel chunks are staged in groups of this many (weights are packed/padded to it)
+int conv_chunk_multiple(int ks);
 // LDS bytes needed by a launch; 0 if the geometry is not supported by `tile`
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a);
 hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& a, hipStream_t st);
@@ -113,6 +118,15 @@ struct BgemmArgs {
   float div;                               // C = acc / div
 };
 hipError_t launch_bgemm(const BgemmArgs& a, hipStream_t st);
+// out[m][n] = sum_s slab[s][m][n] + bias[n] + film[b][n] + resid[m][n]   (split-K epilogue)
+struct SplitKReduceArgs {
+  const float* slab; int nsplit; long long slab_stride;
+  long long M; int N; int HW;            // b = m / HW
+  const float* bias; const float* film; int film_bs;
+  const float* resid; int resid_ld;
+  float* out;
+};
+hipError_t launch_splitk_reduce(const SplitKReduceArgs& a, hipStream_t st);
 hipError_t launch_softmax_rows(float* S, long long rows, int L, hipStream_t st);
 
 // ---------------------------------------------------------------------------

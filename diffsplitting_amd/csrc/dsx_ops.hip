@@ -81,53 +81,46 @@ hipError_t launch_chan_stats(const float* x, int B, int HW, int C, int nchunk, d
 // the two sources (e.g. 128+64 channels / 32 groups).  One workgroup per image.
 //   y = (x-mean)*rstd*gamma + beta  ==  x*scale + shift
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gn_finalize(const GnFinArgs a) {
-  extern __shared__ double sh[];  // [C][2] channel sums, then [groups][2] mean/rstd
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
+  // one wave per (image, group): lanes stride over (channel-in-group, chunk) partials,
+  // fixed assignment + fixed butterfly order -> bitwise reproducible
+  const int b = blockIdx.x, g = blockIdx.y;
+  const int lane = threadIdx.x;
   const int C = a.C0 + a.C1;
-  double* cs = sh;
-  double* gs = sh + 2 * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    double s = 0, q = 0;
-    if (c < a.C0) {
-      for (int ch = 0; ch < a.nchunk0; ++ch) {
-        const double* p = a.part0 + (((size_t)b * a.nchunk0 + ch) * a.C0 + c) * 2;
-        s += p[0]; q += p[1];
-      }
-    } else {
-      for (int ch = 0; ch < a.nchunk1; ++ch) {
-        const double* p = a.part1 + (((size_t)b * a.nchunk1 + ch) * a.C1 + (c - a.C0)) * 2;
-        s += p[0]; q += p[1];
-      }
-    }
-    cs[2 * c] = s; cs[2 * c + 1] = q;
-  }
-  __syncthreads();
   const int cpg = C / a.groups;
-  for (int g = threadIdx.x; g < a.groups; g += 256) {
-    double s = 0, q = 0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += cs[2 * c]; q += cs[2 * c + 1]; }
-    const double n = a.count * cpg;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0) var = 0;
-    gs[2 * g] = mean;
-    gs[2 * g + 1] = 1.0 / sqrt(var + (double)a.eps);
+  const int c_lo = g * cpg;
+  double s = 0, q = 0;
+  // channels of this group that live in source 0 / source 1
+  const int n0 = max(0, min(a.C0, c_lo + cpg) - c_lo);      // first n0 channels from source 0
+  const int items0 = n0 * a.nchunk0;
+  for (int i = lane; i < items0; i += 64) {
+    const int ch = i / n0, c = c_lo + (i - ch * n0);
+    const double* p = a.part0 + (((size_t)b * a.nchunk0 + ch) * a.C0 + c) * 2;
+    s += p[0]; q += p[1];
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int g = c / cpg;
-    const float rstd = (float)gs[2 * g + 1];
-    const float mean = (float)gs[2 * g];
+  const int n1 = cpg - n0;
+  const int items1 = n1 * a.nchunk1;
+  for (int i = lane; i < items1; i += 64) {
+    const int ch = i / n1, c = c_lo + n0 + (i - ch * n1) - a.C0;
+    const double* p = a.part1 + (((size_t)b * a.nchunk1 + ch) * a.C1 + c) * 2;
+    s += p[0]; q += p[1];
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  const double n = a.count * cpg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float meanf = (float)mean;
+  for (int c = c_lo + lane; c < c_lo + cpg; c += 64) {
     const float sc = rstd * a.gamma[c];
     a.scale[(size_t)b * C + c] = sc;
-    a.shift[(size_t)b * C + c] = a.beta[c] - mean * sc;
+    a.shift[(size_t)b * C + c] = a.beta[c] - meanf * sc;
   }
 }
 
 hipError_t launch_gn_finalize(const GnFinArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)(2 * (a.C0 + a.C1) + 2 * a.groups) * sizeof(double);
-  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)a.B), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)a.B, (unsigned)a.groups), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 
@@ -288,6 +281,28 @@ __global__ __launch_bounds__(256) void k_bgemm(const BgemmArgs a) {
 hipError_t launch_bgemm(const BgemmArgs& a, hipStream_t st) {
   const long long tiles = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;
   hipLaunchKernelGGL(k_bgemm, dim3((unsigned)tiles), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// split-K epilogue: sum the slices' slabs, then bias + FiLM + residual (deterministic order)
+__global__ void k_splitk_reduce(const SplitKReduceArgs a) {
+  const long long total = a.M * a.N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / a.N;
+    const int n = (int)(i - m * a.N);
+    float v = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) v += a.slab[(size_t)s * a.slab_stride + i];
+    if (a.bias) v += a.bias[n];
+    if (a.film) v += a.film[(size_t)(m / a.HW) * a.film_bs + n];
+    if (a.resid) v += a.resid[(size_t)m * a.resid_ld + n];
+    a.out[i] = v;
+  }
+}
+hipError_t launch_splitk_reduce(const SplitKReduceArgs& a, hipStream_t st) {
+  long long g = (a.M * a.N + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)g), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -319,7 +319,8 @@ static inline uint16_t f2bf(float f) {
 static void pack_conv(const float* w, int cout, int cin, int ks, int dtype, std::vector<char>& dst,
                       int& kchunks, int& nblocks) {
   const int KC = dtype == 1 ? 32 : 16, EPL = dtype == 1 ? 8 : 4, taps = ks * ks;
-  kchunks = (cin + KC - 1) / KC;
+  const int mult = conv_chunk_multiple(ks);
+  kchunks = ((cin + KC - 1) / KC + mult - 1) / mult * mult;
   nblocks = (cout + 31) / 32;
   dst.assign((size_t)nblocks * kchunks * taps * 2 * 64 * 16, 0);
   for (int nb = 0; nb < nblocks; ++nb)
@@ -547,28 +548,77 @@ static int pow2_divisor(int v, int cap) {  // largest power of two dividing v, <
   return p;
 }
 
-// choose tile + geometry for one conv; returns false if no MFMA config fits
+// tile preference lists, overridable for tuning: DSX_TILES_WIDE / DSX_TILES_NARROW = "0,2,3,4"
+static std::vector<int> tile_order(const char* env, std::initializer_list<int> dflt) {
+  std::vector<int> v(dflt);
+  const char* e = getenv(env);
+  if (e && *e) {
+    v.clear();
+    for (const char* p = e; *p;) {
+      v.push_back(atoi(p));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
+  return v;
+}
+
+// geometry of `tile` for this conv (unsplit); false if the tile cannot be used
+static bool tile_geometry(int dtype, int tile, int ks, int stride, const ConvArgs& a, ConvArgs& c) {
+  if (tile < 0 || tile >= TILE_COUNT) return false;
+  if (stride == 2 && tile != TILE_64x64) return false;
+  const ConvTileInfo ti = conv_tile_info(tile);
+  c = a;
+  const int TW = pow2_divisor(a.Wo, 16);
+  const int TH = pow2_divisor(a.Ho, std::max(1, ti.BM / TW));
+  const int TB = ti.BM / (TW * TH);
+  if (TB < 1 || TW * TH * TB != ti.BM) return false;
+  c.tw_log2 = ilog2(TW); c.th_log2 = ilog2(TH); c.tb_log2 = ilog2(TB);
+  c.tiles_x = a.Wo / TW; c.tiles_y = a.Ho / TH;
+  c.m_tiles = c.tiles_x * c.tiles_y * ((a.B + TB - 1) / TB);
+  c.n_tiles = (c.nblocks * 32 + ti.BN - 1) / ti.BN;
+  c.ksplit = 1; c.groups_per_split = a.kchunks / conv_chunk_multiple(ks); c.slab_stride = 0;
+  return conv_lds_bytes(dtype, tile, ks, stride, c) != 0;
+}
+
+// choose tile + geometry (+ split-K) for one conv; returns false if no MFMA config fits.
+// Pass 1: the first tile of the preference list whose plain grid fills the chip.
+// Pass 2: small-M layers — the first tile of the split list, K split across workgroups
+//         (slabs + a reduce launch) until the grid fills the chip.
 static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out) {
-  const int order_wide[] = {TILE_256x128, TILE_128x64, TILE_64x64};
-  const int order_narrow[] = {TILE_256x64, TILE_128x64, TILE_64x64};
-  const int* order = a.Cout > 64 ? order_wide : order_narrow;
+  static const std::vector<int> wide = tile_order("DSX_TILES_WIDE", {TILE_128x128, TILE_64x128, TILE_64x64});
+  static const std::vector<int> narrow = tile_order("DSX_TILES_NARROW", {TILE_64x64, TILE_128x64});
+  static const std::vector<int> wide2 = tile_order("DSX_TILES_WIDE_SPLIT", {TILE_64x128, TILE_128x128, TILE_64x64});
+  static const std::vector<int> narrow2 = tile_order("DSX_TILES_NARROW_SPLIT", {TILE_64x64, TILE_128x64});
+  static const int min_grid = getenv("DSX_MIN_GRID") ? atoi(getenv("DSX_MIN_GRID")) : 512;
+  static const int splitk_on = getenv("DSX_SPLITK") ? atoi(getenv("DSX_SPLITK")) : 1;
+  const bool is_wide = a.Cout > 64;
+  const int kgroups = a.kchunks / conv_chunk_multiple(ks);
+  ConvArgs c;
+  for (int tile : (is_wide ? wide : narrow)) {
+    if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
+    if ((long long)c.m_tiles * c.n_tiles >= min_grid) { a = c; tile_out = tile; return true; }
+  }
   int best = -1;
+  long long best_eff = -1;
   ConvArgs best_a = a;
-  for (int k = 0; k < 3; ++k) {
-    const int tile = order[k];
-    if (stride == 2 && tile != TILE_64x64) continue;
-    const ConvTileInfo ti = conv_tile_info(tile);
-    ConvArgs c = a;
-    const int TW = pow2_divisor(a.Wo, 16);
-    const int TH = pow2_divisor(a.Ho, std::max(1, ti.BM / TW));
-    const int TB = ti.BM / (TW * TH);
-    c.tw_log2 = ilog2(TW); c.th_log2 = ilog2(TH); c.tb_log2 = ilog2(TB);
-    c.tiles_x = a.Wo / TW; c.tiles_y = a.Ho / TH;
-    c.m_tiles = c.tiles_x * c.tiles_y * ((a.B + TB - 1) / TB);
-    if (conv_lds_bytes(dtype, tile, ks, stride, c) == 0) continue;
-    const int n_tiles = (c.nblocks * 32 + ti.BN - 1) / ti.BN;
-    best = tile; best_a = c;
-    if ((long long)c.m_tiles * n_tiles >= 512) break;
+  for (int tile : (is_wide ? wide2 : narrow2)) {
+    if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
+    const long long grid = (long long)c.m_tiles * c.n_tiles;
+    long long eff = grid;
+    if (splitk_on && grid < min_grid && kgroups >= 4 && (a.Cout % 4) == 0 && a.out_ld == a.Cout) {
+      const int want = (int)((min_grid + grid - 1) / grid);
+      int S = std::min(want, kgroups / 2);  // at least two channel groups per slice
+      const int gps = (kgroups + S - 1) / S;
+      S = (kgroups + gps - 1) / gps;
+      if (S > 1) {
+        c.ksplit = S; c.groups_per_split = gps;
+        c.slab_stride = (long long)a.B * a.Ho * a.Wo * a.Cout;
+        eff = grid * S;
+      }
+    }
+    if (eff > best_eff) { best = tile; best_a = c; best_eff = eff; }
+    if (eff >= min_grid) break;
   }
   if (best < 0) return false;
   a = best_a;
@@ -606,6 +656,11 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   int tile = -1;
   const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
   ex->launches++;
+  float* slab = nullptr;
+  if (mfma_ok && a.ksplit > 1) {
+    slab = (float*)ws_alloc(ex, (size_t)a.ksplit * a.slab_stride * sizeof(float));
+    ex->launches++;
+  }
   if (ex->sizing) return DSX_OK;
   const double npix = (double)a.B * a.Ho * a.Wo;
   const double cin = a.C0 + a.C1;
@@ -614,10 +669,25 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   const double bytes = 4.0 * ((double)a.B * a.Hs * a.Ws * cin + npix * a.Cout * (a.resid ? 2 : 1)) + wbytes;
   if (mfma_ok) {
     const ConvTileInfo ti = conv_tile_info(tile);
-    add_op(ex, DSX_OP_CONV_MFMA,
-           fmt("conv%dx%d%s%s %d->%d @%dx%d tile%dx%d", ks, ks, stride == 2 ? "s2" : "", a.up ? "up" : "",
-               (int)cin, a.Cout, a.Ho, a.Wo, ti.BM, ti.BN),
-           flops, bytes, [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
+    const std::string d = fmt("conv%dx%d%s%s %d->%d @%dx%d tile%dx%d", ks, ks, stride == 2 ? "s2" : "",
+                              a.up ? "up" : "", (int)cin, a.Cout, a.Ho, a.Wo, ti.BM, ti.BN);
+    if (a.ksplit > 1) {
+      ConvArgs p = a;  // slices write raw sums into slabs; a reduce launch applies the epilogue
+      p.out = slab;
+      SplitKReduceArgs ra{};
+      ra.slab = slab; ra.nsplit = a.ksplit; ra.slab_stride = a.slab_stride;
+      ra.M = (long long)a.B * a.Ho * a.Wo; ra.N = a.Cout; ra.HW = a.Ho * a.Wo;
+      ra.bias = a.bias; ra.film = a.film; ra.film_bs = a.film_bs;
+      ra.resid = a.resid; ra.resid_ld = a.resid_ld; ra.out = a.out;
+      add_op(ex, DSX_OP_CONV_MFMA, d + fmt(" splitK%d", a.ksplit), flops, bytes,
+             [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, p, st); });
+      add_op(ex, DSX_OP_SPLITK_REDUCE, fmt("splitk_reduce x%d %d ch @%dx%d", a.ksplit, a.Cout, a.Ho, a.Wo), 0.0,
+             4.0 * (a.ksplit + 1) * (double)ra.M * ra.N,
+             [=](hipStream_t st) { return launch_splitk_reduce(ra, st); });
+    } else {
+      add_op(ex, DSX_OP_CONV_MFMA, d, flops, bytes,
+             [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
+    }
   } else {
     if (!s.w->naive)
       return fail(DSX_ERR_INVALID,

@@ -105,7 +105,7 @@ int dsx_exec_num_launches(const dsx_exec* ex);
 /* Launch-level introspection for measurement (bench.py roofline): the plan's
  * launches in order, what each computes, and an eager hipEvent-timed replay. */
 enum { DSX_OP_CONV_MFMA = 0, DSX_OP_CONV_NAIVE = 1, DSX_OP_GN_STATS = 2, DSX_OP_GN_FINALIZE = 3,
-       DSX_OP_ATTN_GEMM = 4, DSX_OP_SOFTMAX = 5 };
+       DSX_OP_ATTN_GEMM = 4, DSX_OP_SOFTMAX = 5, DSX_OP_SPLITK_REDUCE = 6 };
 int dsx_exec_num_ops(const dsx_exec* ex);
 int dsx_exec_op_info(const dsx_exec* ex, int index, char* desc_buf, int desc_cap, int* kind,
                      double* flops, double* bytes);
