@@ -1,0 +1,3 @@
+"""model/ddpm_modules/diffusion.py of the reference (sampling half, HIP engine)."""
+from ..samplers import GaussianSamplerDdpm as GaussianDiffusion  # noqa: F401
+from ...engine import make_beta_schedule  # noqa: F401

@@ -1,0 +1,75 @@
+"""One process per GPU (torchrun): tile / batch sharding and the single
+collective the sampling path needs — an all-gather of the finished tiles
+(RCCL over xGMI with backend "nccl"; "gloo" on CPU for tests).
+
+Tiles are independent, so the loop itself has no data-path collective: rank r
+owns tiles ``r, r+W, r+2W, …`` (keeps every rank's share spread over frames),
+runs its reverse loops, then all ranks exchange predictions once.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for 1 process)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return rank(), world_size()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend)
+    return rank(), world_size()
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_ids(total, rank_, world):
+    """Tile ids owned by ``rank_``: i ≡ rank (mod world)."""
+    return list(range(rank_, total, world))
+
+
+def shard_count(total, rank_, world):
+    return (total - rank_ + world - 1) // world if rank_ < total else 0
+
+
+def all_gather_tiles(local, total, group=None):
+    """``local``: this rank's predictions (n_local, C, h, w) for tile ids
+    ``shard_ids(total, rank, world)``.  Returns (total, C, h, w) ordered by tile id on
+    every rank.  One padded all-gather (equal counts per rank, as RCCL wants)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    r = dist.get_rank(group)
+    per = (total + world - 1) // world
+    n_local = shard_count(total, r, world)
+    assert local.shape[0] == n_local, (local.shape, n_local)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:n_local] = local
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    out = out.view((world, per) + tuple(local.shape[1:]))
+    # rank q's k-th tile has id q + k*world  ->  interleave back to id order
+    full = out.transpose(0, 1).reshape((per * world,) + tuple(local.shape[1:]))
+    return full[:total].contiguous()
+
+
+def all_gather_batch(x, group=None):
+    """Replica-parallel samplers (SR3 benchmark): concatenate every rank's finished batch."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return x
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""``split.py`` — the reference's entry point (split.py:75-85 flags) for the
+validation / tiled-prediction path on MI355X:
+
+    python -m diffsplitting_amd.split -c config/splitting_hagen_indi.json -p val -gpu 0
+    torchrun --nproc-per-node 8 -m diffsplitting_amd.split -c <config> -p val -gpu 0,1,2,3,4,5,6,7
+
+The config file is consumed unchanged (JSON with // comments).  Frames come
+from ``--frames <file.npy>`` ((N,H,W,2) raw channels) or are synthesised when
+the config's data paths do not exist on this machine.  ``-p train`` is refused:
+the engine is inference-only.
+"""
+import argparse
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import parallel
+from .core import logger as Logger
+from .core.psnr import RangeInvariantPsnr
+from .data.tiled_predict import predict_tiled
+from .model import create_model
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-c", "--config", type=str, required=True, help="JSON file for configuration")
+    ap.add_argument("-p", "--phase", type=str, choices=["train", "val"], default="val")
+    ap.add_argument("-gpu", "--gpu_ids", type=str, default="0")
+    ap.add_argument("-debug", "-d", action="store_true")
+    ap.add_argument("-enable_wandb", action="store_true")
+    ap.add_argument("-rootdir", type=str, default=".")
+    ap.add_argument("--frames", type=str, default=None, help=".npy with (N,H,W,2) raw channel frames")
+    ap.add_argument("--synthetic", type=str, default="2,512,512", help="N,H,W of synthetic frames")
+    ap.add_argument("--steps", type=int, default=None, help="override beta_schedule.val.n_timestep")
+    ap.add_argument("--batch-tiles", type=int, default=8)
+    ap.add_argument("--dtype", type=str, default=None, choices=["f32", "bf16"])
+    args = ap.parse_args(argv)
+    if args.phase == "train":
+        raise SystemExit("training is out of scope of the MI355X sampling engine; use -p val")
+
+    rank, world = parallel.init()
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(message)s")
+    log = logging.getLogger("base")
+    opt = Logger.parse(args)
+    if args.dtype:
+        opt["model"]["compute_dtype"] = args.dtype
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.backends.cudnn.benchmark = True
+
+    diffusion = create_model(opt)
+    diffusion.set_new_noise_schedule(opt["model"]["beta_schedule"]["val"], schedule_phase="val")
+    netG = diffusion.netG
+    n_steps = args.steps or opt["model"]["beta_schedule"]["val"]["n_timestep"]
+
+    if args.frames:
+        frames = np.load(args.frames, allow_pickle=False).astype(np.float32)
+    else:
+        n, h, w = (int(v) for v in args.synthetic.split(","))
+        rng = np.random.default_rng(0)
+        frames = rng.random((n, h, w, 2), dtype=np.float32)
+        log.info("no --frames given: using synthetic frames %s", frames.shape)
+    # per-channel standardisation (stand-in for compute_normalization_dict, split_dataset.py:29-74)
+    mean = frames.mean(axis=(0, 1, 2), keepdims=True)
+    std = frames.std(axis=(0, 1, 2), keepdims=True)
+    target = torch.from_numpy((frames - mean) / std).to(dev)
+    inp = target.mean(dim=-1)                                         # notebook cell 23: input = target.mean(0)
+    patch = opt["datasets"]["val"]["patch_size"] if opt["datasets"] and opt["datasets"]["val"] else 512
+    patch = min(int(patch or 512), target.shape[1], target.shape[2])
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pred, plan = predict_tiled(netG, inp.contiguous(), patch, batch_tiles=args.batch_tiles,
+                               sampler_kwargs=dict(num_timesteps=n_steps))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        log.info("tiled prediction: %d tiles of %d^2, %d steps, %d GPU(s): %.3f s (%.1f tiles/s)",
+                 plan.total, patch, n_steps, world, dt, plan.total / dt)
+        for c in range(min(pred.shape[-1], target.shape[-1])):
+            ps = RangeInvariantPsnr(target[..., c], pred[..., c])
+            log.info("channel %d: RangeInvariantPsnr %.2f +- %.2f dB (random-init weights unless a checkpoint "
+                     "was given in path.resume_state)", c, ps.mean().item(), ps.std().item() if len(ps) > 1 else 0.0)
+    return pred
+
+
+if __name__ == "__main__":
+    main()

@@ -209,3 +209,11 @@ for name, data_shape, grid_shape, patch_shape in cases.TILE_CASES:
         pred = rng.standard_normal((T, 2, patch_shape[1], patch_shape[2])).astype(np.float32)
         arrs["stitched"] = stitch_predictions(pred, mng)
     save(f"tiles_{name}", **arrs)
+
+# ---------------------------------------------------------------- PSNR metrics (core/psnr.py)
+from core.psnr import PSNR, RangeInvariantPsnr  # noqa: E402
+gp = torch.Generator().manual_seed(9)
+gt = torch.randn((3, 40, 56), generator=gp) * 2 + 1
+pred = 0.7 * gt + 0.3 * torch.randn((3, 40, 56), generator=gp) - 0.5
+save("psnr", gt=gt.numpy(), pred=pred.numpy(), psnr=PSNR(gt, pred).numpy(),
+     ri_psnr=RangeInvariantPsnr(gt, pred).numpy())

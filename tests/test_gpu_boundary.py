@@ -1,0 +1,203 @@
+"""The drop-in boundary on the MI355X: define_G / create_model / DDPM.test() /
+tiled prediction / split.py behave like the reference's (checked against the
+CPU oracle and golden vectors).  `-m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, samplers, tiling
+from oracle.weights import synth_state_dict
+from tests.gpu_util import DrawRecorder, maxabs
+from tests.util import GOLDEN, golden_state_dict, load_golden
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+FP32_TOL = 1e-3
+
+
+def _opt(model_section, **extra):
+    from diffsplitting_amd.core.logger import dict_to_nonedict
+    d = {"model": json.loads(json.dumps(model_section)), "phase": "val", "gpu_ids": [0], "distributed": False,
+         "path": {"resume_state": None}}
+    d.update(extra)
+    return dict_to_nonedict(d)
+
+
+def _tiny_indi_section(in_ch=2, out_ch=2, which="indi"):
+    return {"which_model_G": which, "loss_type": "l1", "lr_reduction": "mean", "finetune_norm": False,
+            "w_input_loss": 0.0,
+            "unet": {"in_channel": in_ch, "out_channel": out_ch, "inner_channel": 16, "norm_groups": 16,
+                     "channel_multiplier": [1, 2, 4] if which == "indi" else [1, 2, 4, 8], "attn_res": [],
+                     "res_blocks": 1, "dropout": 0},
+            "beta_schedule": {"train": {"schedule": "linear", "n_timestep": 20, "linear_start": 1e-6, "linear_end": 1e-2},
+                              "val": {"schedule": "linear", "n_timestep": 3, "linear_start": 1e-6, "linear_end": 1e-2}},
+            "diffusion": {"image_size": 32, "channels": out_ch, "conditional": False}}
+
+
+def test_create_model_indi_test_matches_oracle():
+    """create_model -> load_state_dict(reference keys) -> feed_data -> test(): same output as the oracle's
+    InDI.inference, including the 'last batch element only' return (Q1) and the full-batch accessor."""
+    from diffsplitting_amd.model import create_model
+    sd, g = golden_state_dict("loop_indi_n3_t1.0")
+    model = create_model(_opt(_tiny_indi_section()))
+    model.netG.load_state_dict({"denoise_fn." + k: v for k, v in sd.items()}, strict=True)
+    model.set_new_noise_schedule({"n_timestep": 3}, schedule_phase="val")
+    x_in = cases.make_cond("indi_loop")
+    torch.manual_seed(cases.LOOP_SEED)                 # same CPU draws as the golden run
+    model.netG.noise_source = lambda shape: torch.randn(shape)
+    model.feed_data({"input": x_in.clone(), "target": torch.zeros(3, 2, 32, 48)})
+    model.test(continuous=False)
+    vis = model.get_current_visuals()
+    assert vis["prediction"].shape == (1, 2, 32, 48)
+    assert maxabs(vis["prediction"].numpy(), g["last"]) <= FP32_TOL
+    torch.manual_seed(cases.LOOP_SEED)
+    model.test(continuous=True)
+    assert maxabs(model.get_current_visuals()["prediction"].numpy(), g["ret"]) <= FP32_TOL
+    assert model.netG.last_full_batch.shape == (3, 2, 32, 48)
+
+
+def test_define_G_sr3_superset_route():
+    """R1/R2: define_G builds 'sr3' and DDPM.test() routes to super_resolution; output equals the oracle loop."""
+    from diffsplitting_amd.model import create_model
+    sd, g = golden_state_dict("loop_sr3_lin_8")
+    case = cases.UNET_CASES["sr3_tiny"]["cfg"]
+    sec = {"which_model_G": "sr3", "finetune_norm": False,
+           "unet": {"in_channel": 6, "out_channel": 3, "inner_channel": 32, "norm_groups": 32,
+                    "channel_multiplier": [1, 2, 4], "attn_res": [16], "res_blocks": 2, "dropout": 0.2},
+           "beta_schedule": {"train": cases.SCHEDULES["lin_8"], "val": cases.SCHEDULES["lin_8"]},
+           "diffusion": {"image_size": 32, "channels": 3, "conditional": True}}
+    model = create_model(_opt(sec))
+    missing, unexpected = model.netG.load_state_dict({"denoise_fn." + k: v for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(not k.startswith("denoise_fn.") for k in missing)
+    cond = cases.make_cond("sr3_loop")
+    torch.manual_seed(cases.LOOP_SEED)
+    model.netG.noise_source = lambda shape: torch.randn(shape)
+    model.feed_data({"input": cond.clone(), "target": cond.clone()})
+    model.test(continuous=True)
+    assert maxabs(model.get_current_visuals()["prediction"].numpy(), g["ret"]) <= FP32_TOL
+    torch.manual_seed(cases.LOOP_SEED)
+    model.test(continuous=False)
+    pred = model.get_current_visuals()["prediction"].numpy()
+    assert pred.shape == (3, 32, 32) and maxabs(pred, g["last"]) <= FP32_TOL
+    # the schedule buffers are registered under the reference's names
+    keys = set(model.netG.state_dict())
+    assert {"betas", "posterior_mean_coef1", "sqrt_recipm1_alphas_cumprod"} <= keys
+
+
+def test_joint_indi_module():
+    from diffsplitting_amd.model import networks
+    sd, g = golden_state_dict("loop_joint_n3")
+    sec = _tiny_indi_section(1, 1, "joint_indi")
+    netG = networks.define_G(_opt(sec)).cuda()
+    netG.load_state_dict(sd, strict=True)
+    netG.set_new_noise_schedule({"n_timestep": 3}, "cuda")
+    x_in = cases.make_cond("joint_loop").cuda()
+    torch.manual_seed(cases.LOOP_SEED)
+    netG.noise_source = lambda shape: torch.randn(shape)
+    ret = netG.inference(x_in, continuous=True, t_float_start=0.5)
+    assert maxabs(ret.cpu().numpy(), g["ret"]) <= FP32_TOL
+    torch.manual_seed(cases.LOOP_SEED)
+    last = netG.inference(x_in, continuous=False, t_float_start=0.3)
+    assert maxabs(last.cpu().numpy(), g["last_t03"]) <= FP32_TOL
+    # device-noise mode: both loops on two HIP streams, full batch available
+    netG.noise_source = None
+    out = netG.inference(x_in, continuous=False)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 2, 32, 32) and netG.last_full_batch.shape == (2, 2, 32, 32)
+    assert torch.isfinite(netG.last_full_batch).all()
+
+
+def test_time_predictor_module():
+    from diffsplitting_amd.model.ddpm_modules.time_predictor import TimePredictor
+    sd, g = golden_state_dict("time_predictor")
+    tp = TimePredictor(**cases.TIME_PRED_CFG).cuda()
+    tp.load_state_dict(sd, strict=True)
+    t = tp(cases.make_cond("time_pred").cuda())
+    assert maxabs(t.cpu().numpy(), g["t"]) <= FP32_TOL
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """save_network / load_network (model/model.py:131-173) with the reference's file naming."""
+    from diffsplitting_amd.model import create_model
+    sd, _ = golden_state_dict("loop_indi_n3_t1.0")
+    opt = _opt(_tiny_indi_section())
+    opt["path"]["checkpoint"] = str(tmp_path)
+    m1 = create_model(opt)
+    m1.netG.load_state_dict({"denoise_fn." + k: v for k, v in sd.items()})
+    m1.save_network(epoch=1, iter_step=10)
+    assert os.path.exists(tmp_path / "I10_E1_gen.pth")
+    opt2 = _opt(_tiny_indi_section())
+    opt2["path"]["resume_state"] = str(tmp_path / "I10_E1")
+    m2 = create_model(opt2)
+    x = cases.make_cond("indi_loop").cuda()
+    for m in (m1, m2):
+        m.netG.e = 0.0
+    a = m1.netG.inference(x, num_timesteps=2)
+    b = m2.netG.inference(x, num_timesteps=2)
+    assert torch.equal(a, b)
+
+
+def test_tiled_prediction_matches_reference_procedure():
+    """predict_tiled (batched gather -> sampler -> stitch on the device) equals the reference's
+    procedure (one tile per inference call, numpy stitch) done with the oracle; e = 0 so no RNG."""
+    from diffsplitting_amd.data.tiled_predict import predict_tiled
+    from diffsplitting_amd.model import networks
+    sd, _ = golden_state_dict("unet_hagen_64")
+    sec = _tiny_indi_section()
+    sec["unet"]["channel_multiplier"] = [1, 2, 4, 8]
+    netG = networks.define_G(_opt(sec)).cuda()
+    netG.load_state_dict({"denoise_fn." + k: v for k, v in sd.items()})
+    netG.e = 0.0
+    rng = np.random.default_rng(5)
+    frames = rng.standard_normal((2, 96, 160)).astype(np.float32)
+    pred, plan = predict_tiled(netG, torch.from_numpy(frames).cuda(), patch_size=64, grid_size=32, batch_tiles=5,
+                               sampler_kwargs=dict(num_timesteps=2))
+    oplan = tiling.TilePlan((2, 96, 160), (1, 32, 32), (1, 64, 64))
+    assert plan.total == oplan.total() == 2 * 2 * 4
+    osd = {"denoise_fn." + k: v for k, v in sd.items()}
+    cfg = cases.UNET_CASES["hagen_64"]["cfg"]
+    tiles = []
+    for i in range(oplan.total()):
+        n, y, x = oplan.patch_location(i)
+        t_in = torch.from_numpy(frames[n, y:y + 64, x:x + 64])[None, None]
+        out = samplers.indi_inference(osd, cfg, t_in, 2, 2, randn=lambda s: torch.zeros(s), e=0.0)
+        tiles.append(out[0].numpy())
+    ref = tiling.stitch(np.stack(tiles), oplan)
+    assert pred.shape == (2, 96, 160, 2)
+    assert maxabs(pred.cpu().numpy(), ref) <= FP32_TOL
+
+
+def test_stitch_predictions_mirror_numpy():
+    from diffsplitting_amd.data.split_dataset_tiledpred import SplitDatasetTiledPred
+    from diffsplitting_amd.data.tile_stitcher import stitch_predictions
+    data = np.arange(3 * 128 * 128 * 2).reshape(3, 128, 128, 2).astype(np.float32)
+    dset = SplitDatasetTiledPred(data, patch_size=64, grid_size=32)
+    preds = np.stack([dset[i]["target"] for i in range(len(dset))])
+    out = stitch_predictions(preds, dset.tile_manager)
+    assert isinstance(out, np.ndarray) and np.array_equal(out, data)   # tests/test_tiling_setup.py invariant
+
+
+def test_split_entry_point(tmp_path):
+    """`split.py -c <config> -p val` on a config in the reference's schema (with // comments), synthetic frames."""
+    from diffsplitting_amd import split
+    sec = _tiny_indi_section()
+    cfg = {"name": "tiny_hagen_indi", "phase": "train", "gpu_ids": [0],
+           "path": {"log": "logs", "results": "results", "checkpoint": "checkpoint", "resume_state": None},
+           "datasets": {"val": {"name": "Hagen", "patch_size": 64, "datatype": "img"}}, "model": sec}
+    text = json.dumps(cfg, indent=2).replace('"name": "tiny_hagen_indi",', '"name": "tiny_hagen_indi", // comment')
+    p = tmp_path / "tiny.json"
+    p.write_text(text)
+    pred = split.main(["-c", str(p), "-p", "val", "-gpu", "0", "-rootdir", str(tmp_path), "--synthetic", "2,128,128",
+                       "--steps", "2", "--batch-tiles", "4"])
+    assert pred.shape == (2, 128, 128, 2) and torch.isfinite(pred).all()
+
+
+def test_psnr_metrics_on_device():
+    from diffsplitting_amd.core.psnr import PSNR, RangeInvariantPsnr
+    g = load_golden("psnr")
+    gt, pred = torch.from_numpy(g["gt"]).cuda(), torch.from_numpy(g["pred"]).cuda()
+    assert maxabs(PSNR(gt, pred).cpu().numpy(), g["psnr"]) < 1e-3
+    assert maxabs(RangeInvariantPsnr(gt, pred).cpu().numpy(), g["ri_psnr"]) < 1e-3

@@ -161,3 +161,42 @@ def test_snapshot_schedules():
     assert len(s) == 10 and s[-1] == 1999 and [1999 - k for k in s][::-1][:3] == [0, 201, 402]
     assert engine.indi_snapshot_steps(3) == [0, 1, 2] and engine.indi_snapshot_steps(1) == [0]
     assert engine.indi_snapshot_steps(100)[-1] == 99
+
+
+def test_psnr_matches_reference_cpu():
+    from diffsplitting_amd.core.psnr import PSNR, RangeInvariantPsnr
+    g = load_golden("psnr")
+    gt, pred = torch.from_numpy(g["gt"]), torch.from_numpy(g["pred"])
+    assert np.allclose(PSNR(gt, pred).numpy(), g["psnr"], atol=1e-4)
+    assert np.allclose(RangeInvariantPsnr(gt, pred).numpy(), g["ri_psnr"], atol=1e-4)
+
+
+def test_define_G_state_dict_keys_all_baseline_configs():
+    """define_G(opt) builds every config of the reference (incl. sr3/ddpm: rot R1) and its
+    state_dict carries exactly the reference's keys and shapes."""
+    from diffsplitting_amd.core.logger import dict_to_nonedict
+    from diffsplitting_amd.model import networks
+    blob = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    for name, section in blob["model"].items():
+        opt = dict_to_nonedict({"model": section, "phase": "val", "gpu_ids": None, "distributed": False})
+        netG = networks.define_G(opt)
+        mine = [(k, list(v.shape)) for k, v in netG.state_dict().items()]
+        assert mine == [(k, list(s)) for k, s in blob["keys"][name]], name
+        assert opt["model"]["unet"]["norm_groups"] is not None          # define_G fills it (Q9)
+
+
+def test_model_refuses_cpu_inference():
+    from diffsplitting_amd._lib import DsxError
+    from diffsplitting_amd.model.ddpm_modules.unet import UNet
+    net = UNet(in_channel=2, out_channel=2, inner_channel=16, norm_groups=16, channel_mults=(1, 2), attn_res=(),
+               res_blocks=1, image_size=32)
+    with pytest.raises(DsxError):
+        net(torch.zeros(1, 2, 32, 32), torch.tensor([0.5]))
+
+
+def test_config_loader_strips_comments(tmp_path):
+    from diffsplitting_amd.core.logger import dict_to_nonedict, load_json
+    p = tmp_path / "c.json"
+    p.write_text('{\n "a": 1, // trailing comment\n "b": {"c": [1, 2]} // another\n}\n')
+    opt = dict_to_nonedict(load_json(str(p)))
+    assert opt["a"] == 1 and opt["b"]["c"] == [1, 2] and opt["missing"] is None and opt["b"]["zzz"] is None
