@@ -28,6 +28,8 @@ class _SamplerBase(nn.Module):
         return torch.randn(tuple(shape), device=device)
 
     def _seed(self):
+        if self.noise_source is not None:
+            return 0   # injected noise: leave torch's generator untouched (the draws must stay in order)
         return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
 
     def forward(self, x, *args, **kwargs):
