@@ -25,6 +25,10 @@
 //                  store instruction writes 2 x 128 B contiguous NHWC segments.
 #include "dsx_kernels.h"
 
+#ifndef DSX_RING_DEPTH
+#define DSX_RING_DEPTH 6  // weight-fragment prefetch ring depth for 3x3 (divides 18)
+#endif
+
 namespace dsx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -35,12 +39,34 @@ __device__ __forceinline__ float swish_f(float v) {
   return __fdividef(v, 1.0f + __expf(-v));
 }
 
+// sum over the 16 lanes of a DPP row; every lane of the row ends up with the total
+__device__ __forceinline__ float row16_sum(float v) {
+  int x;
+  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, x);
+  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, x);
+  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false);  // row_ror:4
+  v += __builtin_bit_cast(float, x);
+  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false);  // row_ror:8
+  v += __builtin_bit_cast(float, x);
+  return v;
+}
+
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   __bf16 l = (__bf16)lo, h = (__bf16)hi;  // RNE (v_cvt_pk_bf16_f32)
   unsigned short ls = __builtin_bit_cast(unsigned short, l);
   unsigned short hs = __builtin_bit_cast(unsigned short, h);
   return (unsigned)ls | ((unsigned)hs << 16);
 }
+
+// diagnostic stamps (DSX_STAMP_OP): wave 0 of one chosen workgroup records s_memtime at phase
+// boundaries into a debug buffer that nothing else reads; off (nullptr) in normal runs
+#define DSX_STAMP(i)                                                                        \
+  do {                                                                                      \
+    if (a.stamp != nullptr && blockIdx.x == (unsigned)a.stamp_block && tid == 0 && (i) < 120) \
+      a.stamp[(i)] = __builtin_amdgcn_s_memtime();                                          \
+  } while (0)
 
 template <typename DT> struct Chunk;
 template <> struct Chunk<float> { static constexpr int KC = 16; };
@@ -50,6 +76,12 @@ template <> struct Chunk<__bf16> { static constexpr int KC = 32; };
 //        32-channel N block, so with WM == 1 no weight fragment is loaded twice.
 // CPG  : channel chunks staged per barrier ("group"); 1 for 3x3, 2 for 1x1 (few steps per chunk)
 // D    : depth of the weight-fragment prefetch ring (global -> VGPR), steps ahead
+//
+// Addressing is done by the memory pipeline, not the VALU: both operands come through
+// buffer_load with a wave-uniform SGPR offset; out-of-range offsets (zero padding, channel
+// tails, prefetch past the end) return 0 from the hardware bounds check, so the staging
+// code has no predicates.  LDS image: pixel stride PIXB, row pitch `a.lds_row` chosen by the
+// host so that ds_read_b128 of a 32-row fragment is bank-conflict-free (see conv_lds_row).
 template <typename DT, int MB, int WM, int WN, int KS, int S, int CPG, int D, int MAX_IT>
 __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   constexpr int KC = Chunk<DT>::KC;
@@ -57,7 +89,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   constexpr int UPG = UPP * CPG;              // ... per group
   constexpr int UPG_LOG2 = UPG == 16 ? 4 : (UPG == 8 ? 3 : 2);
   constexpr int UB = 4 * (int)sizeof(DT);     // LDS bytes per staging unit
-  constexpr int PIXB = 64 * CPG + 16;         // LDS bytes per patch pixel (odd multiple of 16: conflict-free b128 reads)
+  constexpr int PIXB = 64 * CPG + 16;         // LDS bytes per patch pixel
   constexpr int TAPS = KS * KS;
   constexpr int PAD = KS / 2;
   constexpr int NSTEP = CPG * TAPS * 2;       // MFMA steps per group: (chunk, tap, 32-B half)
@@ -69,7 +101,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -78,7 +110,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   const int PH = (TH - 1) * S + KS;
   const int PPI = PH * PW;                       // patch pixels per image
   const int PP = PPI << a.tb_log2;               // patch pixels per tile
-  const int BUFB = (PP * PIXB + 15) & ~15;
+  const int RB = a.lds_row;                      // LDS bytes per patch row
+  const int BUFB = (PH << a.tb_log2) * RB;       // one LDS buffer
   const bool multi_img = a.tb_log2 != 0;
 
   // ---- tile coordinates: blockIdx.x = (split * n_tiles + nt) * m_tiles + mt
@@ -98,53 +131,75 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   const int g0 = split * a.groups_per_split;
   const int g1 = min(kgroups, g0 + a.groups_per_split);
 
-  // ---- staging plan: which source pixel feeds each of this thread's units
+  // ---- staging plan: source pixel and LDS slot of each of this thread's units.
+  // Unit u = tid + 256*it covers patch pixel u >> UPG_LOG2; (tb, py, px) advance by a fixed stride
+  // per `it`, so only the first unit needs integer divisions.
   const int nunits = PP << UPG_LOG2;
-  int soff[MAX_IT];   // source pixel index, or -1 (zero padding / outside batch)
-  int simg[MAX_IT];   // image index (GroupNorm scale/shift lookup when a tile spans images)
-#pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) {
-    const int u = tid + it * 256;
-    const int pix = u >> UPG_LOG2;
-    int so = -1, b = b0;
-    if (u < nunits) {
-      const int tb = pix / PPI;
-      const int rem = pix - tb * PPI;
-      const int py = rem / PW;
-      const int px = rem - py * PW;
-      const int iy = iy0 + py, ix = ix0 + px;
-      b = b0 + tb;
-      if (b < a.B && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
-        const int sy = a.up ? (iy >> 1) : iy;
-        const int sx = a.up ? (ix >> 1) : ix;
-        so = (b * a.Hs + sy) * a.Ws + sx;
-      }
-    }
-    soff[it] = so;
-    simg[it] = b;
-  }
   const int cvg = tid & (UPG - 1);  // this thread's 4-channel unit inside a group (same for all its units)
+  int soff[MAX_IT];   // source pixel index, or -1 (zero padding / outside batch / no such unit)
+  int loff[MAX_IT];   // LDS byte offset of the unit inside a buffer, or -1
+  int simg[MAX_IT];   // image index (GroupNorm scale/shift lookup when a tile spans images)
+  {
+    constexpr int PSTEP = 256 >> UPG_LOG2;           // pixels between consecutive units of a thread
+    const int pix0 = tid >> UPG_LOG2;
+    int tb = pix0 / PPI;
+    int rem = pix0 - tb * PPI;
+    int py = rem / PW;
+    int px = rem - py * PW;
+    const int dpy = PSTEP / PW, dpx = PSTEP - dpy * PW;   // uniform
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      int so = -1, lo = -1;
+      const int b = b0 + tb;
+      if (tid + it * 256 < nunits) {
+        const int iy = iy0 + py, ix = ix0 + px;
+        lo = (tb * PH + py) * RB + px * PIXB + cvg * UB;
+        if (b < a.B && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
+          const int sy = a.up ? (iy >> 1) : iy;
+          const int sx = a.up ? (ix >> 1) : ix;
+          so = (b * a.Hs + sy) * a.Ws + sx;
+        }
+      }
+      soff[it] = so;
+      loff[it] = lo;
+      simg[it] = b;
+      px += dpx; py += dpy;
+      if (px >= PW) { px -= PW; py += 1; }
+      while (py >= PH) { py -= PH; tb += 1; }
+    }
+  }
 
-  // ---- A-fragment LDS base offsets for this wave's MB row blocks
-  int abase[MB];
+  // ---- A-fragment LDS addresses: one per (row block, tap row); tap column / chunk / half are immediates
+  int abase[MB][KS];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = (wm * MB + mb) * 32 + li;
     const int tx = m & (TW - 1);
     const int ty = (m >> a.tw_log2) & (TH - 1);
     const int tb = m >> (a.tw_log2 + a.th_log2);
-    abase[mb] = ((tb * PH + ty * S) * PW + tx * S) * PIXB + lh * 16;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+      abase[mb][dy] = (tb * PH + ty * S + dy) * RB + tx * S * PIXB + lh * 16;
   }
 
-  // ---- B fragments: fragment-packed weights, one coalesced 16-B load per lane per step,
-  //      kept D steps ahead in a register ring (the step index runs on across groups)
+  // ---- buffer descriptors (wave-uniform): activations (two sources) and this wave's weight stream
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.src0, 0, (int)min((long long)a.B * a.Hs * a.Ws * a.C0 * 4, 0x7fffffffLL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.src1 ? a.src1 : a.src0), 0,
+      a.src1 ? (int)min((long long)a.B * a.Hs * a.Ws * a.C1 * 4, 0x7fffffffLL) : 0, 0x00020000);
   int blk = nt * WN + wn;
   if (blk >= a.nblocks) blk = a.nblocks - 1;  // results of a clamped block are never stored
-  const uint4* wpb = (const uint4*)a.wpack + (size_t)blk * kgroups * (NSTEP * 64) + lane;
-  const int q_end = g1 * NSTEP;               // one past this workgroup's last step
+  const long long wblock = (long long)kgroups * (NSTEP * 1024);  // bytes of one N block's fragment stream
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const unsigned char*)a.wpack + (size_t)blk * wblock), 0, (int)wblock, 0x00020000);
+  const int wlane = lane * 16;
+  auto load_b = [&](int q) -> uint4 {  // step q of the stream; past the end -> zeros (bounds check)
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, q * 1024, 0));
+  };
   uint4 bq[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) bq[j] = wpb[(size_t)min(g0 * NSTEP + j, q_end - 1) * 64];
+  for (int j = 0; j < D; ++j) bq[j] = load_b(g0 * NSTEP + j);
 
   f32x16 acc[MB];
 #pragma unroll
@@ -153,31 +208,59 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
 
   float4 stg[MAX_IT];
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // issue the global loads of group g into registers
   auto stage_load = [&](int g) {
     const int c = g * (CPG * KC) + cvg * 4;
+    if (a.ablate & 2) return;   // timing experiments only (DSX_ABLATE): skip activation loads
+    if (a.stage_mode == 0) {
+      // fast path (both channel counts multiples of the group width): the whole workgroup reads ONE
+      // source in this group -> wave-uniform descriptor, offsets by the memory pipeline, OOB -> 0
+      const bool first = g * (CPG * KC) < a.C0;            // uniform
+      const int cs = first ? a.C0 : a.C1;
+      const unsigned coff = c < C ? (unsigned)((first ? c : c - a.C0) * 4) : 0x80000000u;
+      if (first) {
 #pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int so = soff[it];
-      if (so >= 0) {
-        if (!a.scalar_stage) {
+        for (int it = 0; it < MAX_IT; ++it) {
+          const unsigned vo = soff[it] >= 0 ? (unsigned)soff[it] * (unsigned)(cs * 4) + coff : 0x80000000u;
+          stg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+          const unsigned vo = soff[it] >= 0 ? (unsigned)soff[it] * (unsigned)(cs * 4) + coff : 0x80000000u;
+          stg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0));
+        }
+      }
+    } else if (a.stage_mode == 1) {
+      // channel counts multiples of 4 but a group may straddle the two sources: per-lane source select
+#pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int so = soff[it];
+        if (so >= 0) {
           if (c < a.C0) v = *(const float4*)(a.src0 + (size_t)so * a.C0 + c);
           else if (c < C) v = *(const float4*)(a.src1 + (size_t)so * a.C1 + (c - a.C0));
-        } else {
-          float e[4];
+        }
+        stg[it] = v;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        const int so = soff[it];
+        if (so >= 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int cc = c + j;
-            e[j] = 0.f;
             if (cc < a.C0) e[j] = a.src0[(size_t)so * a.C0 + cc];
             else if (cc < C) e[j] = a.src1[(size_t)so * a.C1 + (cc - a.C0)];
           }
-          v = make_float4(e[0], e[1], e[2], e[3]);
         }
+        stg[it] = make_float4(e[0], e[1], e[2], e[3]);
       }
-      stg[it] = v;
     }
   };
 
@@ -189,7 +272,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     auto load_affine = [&](int b) {
       const size_t gi = (size_t)b * C + c;
-      if (!a.scalar_stage) {
+      if (!(a.stage_mode == 2)) {
         const float4 s4 = *(const float4*)(a.gn_scale + gi);
         const float4 h4 = *(const float4*)(a.gn_shift + gi);
         sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
@@ -205,10 +288,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
     if (has_gn && !multi_img) load_affine(b0);  // one image per tile: same (b, c) for every unit
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
-      const int u = tid + it * 256;
-      if (u < nunits) {
+      if (loff[it] >= 0) {
         float4 v = stg[it];
-        if (soff[it] >= 0 && c < C) {
+        if (soff[it] >= 0 && c < C && !(a.ablate & 1)) {   // padding pixels stay exactly 0 (padded AFTER the activation)
           if (has_gn) {
             if (multi_img) load_affine(simg[it]);
             v.x = v.x * sc[0] + sh[0];
@@ -219,14 +301,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
           if (a.swish) {
             v.x = swish_f(v.x); v.y = swish_f(v.y); v.z = swish_f(v.z); v.w = swish_f(v.w);
           }
-          if (a.scalar_stage) {  // channels past C inside the last 4-group must stay 0
+          if ((a.stage_mode == 2)) {  // channels past C inside the last 4-group must stay 0
             if (c + 1 >= C) v.y = 0.f;
             if (c + 2 >= C) v.z = 0.f;
             if (c + 3 >= C) v.w = 0.f;
           }
         }
-        const int pix = u >> UPG_LOG2;
-        unsigned char* p = dst + pix * PIXB + cvg * UB;
+        unsigned char* p = dst + loff[it];
         if constexpr (IS_BF16) {
           uint2 w;
           w.x = pack_bf16x2(v.x, v.y);
@@ -240,9 +321,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   };
 
   // ---- main loop over channel groups (double-buffered LDS, one barrier per group)
+  DSX_STAMP(0);
   stage_load(g0);
+  DSX_STAMP(1);
   stage_store(g0, 0);
+  DSX_STAMP(2);
   __syncthreads();
+  DSX_STAMP(3);
 
   for (int g = g0; g < g1; ++g) {
     const bool more = (g + 1) < g1;
@@ -250,61 +335,129 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
     const int qbase = g * NSTEP;
 
     if (more) stage_load(g + 1);
+    DSX_STAMP(8 + 4 * (g - g0));
 
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       const uint4 bcur = bq[s % D];
-      bq[s % D] = wpb[(size_t)min(qbase + s + D, q_end - 1) * 64];
-      const int cg = s / (TAPS * 2), tap = (s >> 1) % TAPS, fs = s & 1;
+      if (!(a.ablate & 4)) bq[s % D] = load_b(qbase + s + D);
+      constexpr int kTapSteps = TAPS * 2;
+      const int cg = s / kTapSteps, tap = (s >> 1) % TAPS, fs = s & 1;
       const int dy = tap / KS, dx = tap % KS;
-      const int aoff = (dy * PW + dx) * PIXB + cg * 64 + fs * 32;
+      const int imm = dx * PIXB + cg * 64 + fs * 32;   // compile-time after unrolling
+      if (a.ablate & 8) continue;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const uint4 av = *(const uint4*)(abuf + abase[mb] + aoff);
+        const uint4 av = *(const uint4*)(abuf + abase[mb][dy] + imm);
         if constexpr (IS_BF16) {
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
-                                                            __builtin_bit_cast(bf16x8, bcur), acc[mb], 0, 0, 0);
+          // weights as the A operand, pixels as B: the accumulator then holds, per lane, one pixel's
+          // channels in groups of 4 consecutive -> 16-B epilogue loads/stores
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur),
+                                                            __builtin_bit_cast(bf16x8, av), acc[mb], 0, 0, 0);
         } else {
           const float4 af = __builtin_bit_cast(float4, av);
           const float4 bf = __builtin_bit_cast(float4, bcur);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af.z, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc[mb], 0, 0, 0);
         }
       }
     }
 
-    if (more) stage_store(g + 1, (g + 1 - g0) & 1);
+    DSX_STAMP(9 + 4 * (g - g0));
+    if (more && !(a.ablate & 32)) stage_store(g + 1, (g + 1 - g0) & 1);
+    DSX_STAMP(10 + 4 * (g - g0));
     __syncthreads();
+    DSX_STAMP(11 + 4 * (g - g0));
   }
+  DSX_STAMP(4);
 
-  // ---- epilogue: NHWC stores; split-K slices write raw partial sums to their slab
-  const int n = (nt * WN + wn) * 32 + li;
-  if (n >= a.Cout) return;
+  // ---- epilogue.  Accumulator layout (operands swapped): column = lane&31 = pixel of the row block,
+  // register r = channel (r&3) + 8*(r>>2) + 4*(lane>>5) of this wave's 32-channel block: every group of
+  // 4 registers is 4 consecutive channels -> float4 bias / FiLM / residual loads and float4 NHWC stores.
+  // Split-K slices write raw partial sums to their slab.  The GroupNorm statistics of the tensor being
+  // written (sum, sum of squares per channel over this wave's pixels) are accumulated in the same pass.
+  if (a.ablate & 16) return;
+  const int nbase = (nt * WN + wn) * 32 + 4 * lh;
   const bool partial = a.ksplit > 1;
   float* outp = a.out + (partial ? (size_t)split * a.slab_stride : 0);
-  const float bias = (!partial && a.bias) ? a.bias[n] : 0.f;
+  const bool vec = (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (!a.resid || (a.resid_ld & 3) == 0);
+  // fused statistics are compiled only into the small-MB tiles: in the MB >= 4 tiles their registers
+  // would cost a wave of occupancy (the host then falls back to k_chan_stats)
+  constexpr bool STATS = MB <= 2;
+  const bool do_stats = STATS && a.stat_part != nullptr;   // host guarantees: vec, one image per tile, no split-K
+  float s1[16], s2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
+    // one row block at a time: keeps the epilogue's loads from being hoisted across blocks,
+    // which would cost registers (and a wave of occupancy) in the main loop's favour
+    __builtin_amdgcn_sched_barrier(0);
+    const int m = (wm * MB + mb) * 32 + li;
+    const int tx = m & (TW - 1);
+    const int ty = (m >> a.tw_log2) & (TH - 1);
+    const int b = b0 + (m >> (a.tw_log2 + a.th_log2));
+    if (b >= a.B) continue;
+    const size_t opix = ((size_t)b * a.Ho + (oy0 + ty)) * a.Wo + (ox0 + tx);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int m = (wm * MB + mb) * 32 + row;
-      const int tx = m & (TW - 1);
-      const int ty = (m >> a.tw_log2) & (TH - 1);
-      const int b = b0 + (m >> (a.tw_log2 + a.th_log2));
-      if (b < a.B) {
-        const size_t opix = ((size_t)b * a.Ho + (oy0 + ty)) * a.Wo + (ox0 + tx);
-        float v = acc[mb][r] + bias;
+    for (int j = 0; j < 4; ++j) {
+      const int n = nbase + 8 * j;
+      if (n >= a.Cout) continue;
+      float v[4] = {acc[mb][4 * j], acc[mb][4 * j + 1], acc[mb][4 * j + 2], acc[mb][4 * j + 3]};
+      if (vec) {
         if (!partial) {
-          if (a.film) v += a.film[(size_t)b * a.film_bs + n];
-          if (a.resid) v += a.resid[opix * a.resid_ld + n];
+          if (a.bias) { const float4 t = *(const float4*)(a.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          if (a.film) { const float4 t = *(const float4*)(a.film + (size_t)b * a.film_bs + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          if (a.resid) { const float4 t = *(const float4*)(a.resid + opix * a.resid_ld + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
         }
-        outp[opix * a.out_ld + n] = v;
+        *(float4*)(outp + opix * a.out_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (do_stats) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { s1[4 * j + k] += v[k]; s2[4 * j + k] += v[k] * v[k]; }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (n + k >= a.Cout) break;
+          float x = v[k];
+          if (!partial) {
+            if (a.bias) x += a.bias[n + k];
+            if (a.film) x += a.film[(size_t)b * a.film_bs + n + k];
+            if (a.resid) x += a.resid[opix * a.resid_ld + n + k];
+          }
+          outp[opix * a.out_ld + n + k] = x;
+        }
       }
     }
   }
+  DSX_STAMP(5);
+
+  // ---- statistics: reduce over the 32 pixel lanes of each half-wave.  Four DPP steps inside the
+  // 16-lane rows (quad swaps, then row rotations) and one cross-row exchange; fixed order ->
+  // bitwise reproducible.  One partial row per (tile, wm): [b][chunk][channel][2] fp32.
+  if (do_stats) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s1[r] = row16_sum(s1[r]);
+      s2[r] = row16_sum(s2[r]);
+    }
+    // lane li < 16 keeps register li, then adds the other 16-lane row's copy (one bpermute each)
+    float w1 = s1[0], w2 = s2[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) { if ((li & 15) == r) { w1 = s1[r]; w2 = s2[r]; } }
+    w1 += __shfl_xor(w1, 16, 64);
+    w2 += __shfl_xor(w2, 16, 64);
+    const int chunk = (tyi * a.tiles_x + txi) * WM + wm;   // partial row inside the image
+    const int nch = a.tiles_x * a.tiles_y * WM;
+    const int n = (nt * WN + wn) * 32 + (li & 3) + 8 * (li >> 2) + 4 * lh;
+    if (li < 16 && n < a.Cout) {
+      float* p = a.stat_part + (((size_t)b0 * nch + chunk) * a.Cout + n) * 2;
+      p[0] = w1; p[1] = w2;
+    }
+  }
+  DSX_STAMP(6);
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -322,6 +475,9 @@ ConvTileInfo conv_tile_info(int tile) {
   const TileCfg& t = kTiles[tile];
   return ConvTileInfo{32 * t.MB * t.WM, 32 * t.WN};
 }
+
+int conv_tile_wm(int tile) { return kTiles[tile].WM; }
+bool conv_tile_fuses_stats(int tile) { return kTiles[tile].MB <= 2; }
 
 static constexpr int conv_cpg(int ks) { return ks == 1 ? 2 : 1; }
 
@@ -343,6 +499,19 @@ static int patch_pixels(int ks, int stride, const ConvArgs& a) {
 
 int conv_chunk_multiple(int ks) { return conv_cpg(ks); }
 
+// LDS bytes per patch row.  The A fragment of a 32-row block is read with ds_read_b128, whose 16-lane
+// groups cover rows {0-3,12-15,20-27} / {4-11,16-19,28-31}: with 16-wide tiles the pitch must be a multiple
+// of 256 B, with 8-wide tiles an odd multiple of 128 B, for the 16 reads to fall on 16 distinct 16-B slots.
+int conv_lds_row(int ks, int stride, int tw_log2) {
+  const int pixb = 64 * conv_cpg(ks) + 16;
+  const int pw = ((1 << tw_log2) - 1) * stride + ks;
+  int rb = (pw * pixb + 15) & ~15;
+  if (ks == 1 || stride != 1) return rb;   // no halo: consecutive pixels already conflict-free
+  if (tw_log2 == 4) rb = (rb + 255) & ~255;
+  else if (tw_log2 == 3) { rb = (rb + 127) & ~127; if (((rb >> 7) & 1) == 0) rb += 128; }
+  return rb;
+}
+
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a) {
   if (tile < 0 || tile >= TILE_COUNT) return 0;
   if (!(ks == 1 || ks == 3) || !(stride == 1 || (stride == 2 && ks == 3 && tile == TILE_64x64))) return 0;
@@ -350,8 +519,9 @@ size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a
   if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != ti.BM) return 0;
   const int pp = patch_pixels(ks, stride, a);
   if (pp > max_px(tile, ks, stride)) return 0;
-  const size_t pixb = 64 * conv_cpg(ks) + 16;
-  const size_t bufb = ((size_t)pp * pixb + 15) & ~(size_t)15;
+  if (a.lds_row != conv_lds_row(ks, stride, a.tw_log2)) return 0;
+  const int ph = ((1 << a.th_log2) - 1) * stride + ks;
+  const size_t bufb = (size_t)(ph << a.tb_log2) * a.lds_row;
   if (2 * bufb > 64 * 1024) return 0;
   return 2 * bufb;
 }
@@ -361,7 +531,7 @@ template <typename DT, int TILE, int KS, int S>
 static hipError_t launch_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
   constexpr TileCfg t = kTiles[TILE];
   constexpr int CPG = conv_cpg(KS);
-  constexpr int D = KS == 1 ? 4 : 6;
+  constexpr int D = KS == 1 ? 4 : DSX_RING_DEPTH;
   constexpr int MI = max_it(sizeof(DT) == 2 ? 1 : 0, TILE, KS, S);
   auto kern = k_conv_mfma<DT, t.MB, t.WM, t.WN, KS, S, CPG, D, MI>;
   if (!ap)

@@ -23,7 +23,8 @@ struct ConvArgs {
   const float* gn_scale;  // [B][C0+C1] or nullptr:  v = x*scale + shift
   const float* gn_shift;
   int swish;              // v = v*sigmoid(v) after the affine
-  int scalar_stage;       // channel counts not multiples of 4: per-element loads
+  int stage_mode;         // 0: sources aligned to the channel group (buffer loads); 1: float4 loads with
+                          // per-lane source select; 2: channel counts not multiples of 4 (per-element loads)
   const void* wpack;      // MFMA-fragment-ordered weights (fp32 or bf16)
   const float* bias;      // [Cout] or nullptr
   const float* film;      // film[b*film_bs + n] or nullptr (FiLM / time-embedding add)
@@ -37,6 +38,11 @@ struct ConvArgs {
   int kchunks;            // ceil((C0+C1)/KC), padded to conv_chunk_multiple(ks)
   int tw_log2, th_log2, tb_log2;  // output tile = TB images x TH x TW pixels
   int tiles_x, tiles_y, m_tiles, n_tiles;
+  int lds_row;            // LDS bytes per patch row (conv_lds_row)
+  float* stat_part;       // fused GroupNorm partials [B][tiles_x*tiles_y*WM][Cout][2] (fp32) or nullptr
+  unsigned long long* stamp;  // diagnostic s_memtime stamps of workgroup `stamp_block` (or nullptr)
+  int stamp_block;
+  int ablate;             // DSX_ABLATE timing experiments (results are wrong when non-zero)
   int ksplit;             // split-K slices (1 = none); slice s writes raw sums to out + s*slab_stride
   int groups_per_split;   // channel groups per slice
   long long slab_stride;  // elements between slabs
@@ -46,8 +52,11 @@ struct ConvArgs {
 enum ConvTile { TILE_256x128 = 0, TILE_128x128, TILE_64x128, TILE_256x64, TILE_128x64, TILE_64x64, TILE_COUNT };
 struct ConvTileInfo { int BM, BN; };
 ConvTileInfo conv_tile_info(int tile);
+int conv_tile_wm(int tile);   // waves along M (one statistics row per (tile, wm))
+bool conv_tile_fuses_stats(int tile);
 // input-channel chunks are staged in groups of this many (weights are packed/padded to it)
 int conv_chunk_multiple(int ks);
+int conv_lds_row(int ks, int stride, int tw_log2);
 // LDS bytes needed by a launch; 0 if the geometry is not supported by `tile`
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a);
 hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& a, hipStream_t st);
@@ -74,8 +83,8 @@ hipError_t launch_chan_stats(const float* x, int B, int HW, int C, int nchunk, d
                              hipStream_t st);
 // GroupNorm of the concatenation of (t0, t1) -> scale/shift[b][C0+C1]
 struct GnFinArgs {
-  const double* part0; int C0, nchunk0;
-  const double* part1; int C1, nchunk1;
+  const void* part0; int C0, nchunk0, f32_0;   // partials: double (k_chan_stats) or float (conv epilogue)
+  const void* part1; int C1, nchunk1, f32_1;
   int B, groups;
   double count;          // elements per channel (H*W)
   const float* gamma;    // [C0+C1]

@@ -95,15 +95,17 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
   const int items0 = n0 * a.nchunk0;
   for (int i = lane; i < items0; i += 64) {
     const int ch = i / n0, c = c_lo + (i - ch * n0);
-    const double* p = a.part0 + (((size_t)b * a.nchunk0 + ch) * a.C0 + c) * 2;
-    s += p[0]; q += p[1];
+    const size_t idx = (((size_t)b * a.nchunk0 + ch) * a.C0 + c) * 2;
+    if (a.f32_0) { const float* p = (const float*)a.part0 + idx; s += p[0]; q += p[1]; }
+    else { const double* p = (const double*)a.part0 + idx; s += p[0]; q += p[1]; }
   }
   const int n1 = cpg - n0;
   const int items1 = n1 * a.nchunk1;
   for (int i = lane; i < items1; i += 64) {
     const int ch = i / n1, c = c_lo + n0 + (i - ch * n1) - a.C0;
-    const double* p = a.part1 + (((size_t)b * a.nchunk1 + ch) * a.C1 + c) * 2;
-    s += p[0]; q += p[1];
+    const size_t idx = (((size_t)b * a.nchunk1 + ch) * a.C1 + c) * 2;
+    if (a.f32_1) { const float* p = (const float*)a.part1 + idx; s += p[0]; q += p[1]; }
+    else { const double* p = (const double*)a.part1 + idx; s += p[0]; q += p[1]; }
   }
   s = wave_sum(s); q = wave_sum(q);
   const double n = a.count * cpg;

@@ -468,9 +468,10 @@ struct Tensor {
   int id = -1;             // index into dsx_exec::stats (copies of a Tensor share it)
 };
 struct StatInfo {          // GroupNorm partial sums of one tensor, produced at most once
-  double* part = nullptr;
+  void* part = nullptr;    // double [B][nchunk][C][2] (k_chan_stats) or float (fused into the conv epilogue)
   int nchunk = 0;
   bool planned = false;
+  bool f32 = false;
 };
 
 struct OpInfo {            // what one launch of the plan computes (for profiling / roofline)
@@ -490,6 +491,8 @@ struct dsx_exec {
   bool sizing = true;
   std::vector<std::function<hipError_t(hipStream_t)>> ops;  // the UNet forward
   std::vector<OpInfo> op_info;                               // parallel to ops
+  int conv_ordinal = 0;
+  unsigned long long* stamp_buf = nullptr;
   std::vector<StatInfo> stats;
   // fixed buffers
   Tensor in_cond, in_x, out;   // NHWC
@@ -578,6 +581,8 @@ static bool tile_geometry(int dtype, int tile, int ks, int stride, const ConvArg
   c.m_tiles = c.tiles_x * c.tiles_y * ((a.B + TB - 1) / TB);
   c.n_tiles = (c.nblocks * 32 + ti.BN - 1) / ti.BN;
   c.ksplit = 1; c.groups_per_split = a.kchunks / conv_chunk_multiple(ks); c.slab_stride = 0;
+  c.lds_row = conv_lds_row(ks, stride, c.tw_log2);
+  c.ablate = getenv("DSX_ABLATE") ? atoi(getenv("DSX_ABLATE")) : 0;
   return conv_lds_bytes(dtype, tile, ks, stride, c) != 0;
 }
 
@@ -636,6 +641,7 @@ struct ConvSpec {
   const float* film = nullptr; int film_bs = 0;
   const float* resid = nullptr; int resid_ld = 0;
   Tensor out;
+  bool want_stats = false;   // a GroupNorm will read `out`: produce its statistics in the epilogue
 };
 
 static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
@@ -645,7 +651,10 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   a.B = ex->B; a.Hs = s.x0.H; a.Ws = s.x0.W; a.up = s.up ? 1 : 0;
   a.Ho = s.out.H; a.Wo = s.out.W;
   a.gn_scale = s.gn_scale; a.gn_shift = s.gn_shift; a.swish = s.swish ? 1 : 0;
-  a.scalar_stage = ((a.C0 & 3) || (a.C1 & 3)) ? 1 : 0;
+  {
+    const int gw = conv_chunk_multiple(s.w->ks) * (ex->m->dtype == 1 ? 32 : 16);  // channels per staged group
+    a.stage_mode = ((a.C0 & 3) || (a.C1 & 3)) ? 2 : ((a.C1 == 0 || a.C0 % gw == 0) ? 0 : 1);
+  }
   a.wpack = s.w->pack; a.bias = s.w->bias;
   a.film = s.film; a.film_bs = s.film_bs;
   a.resid = s.resid; a.resid_ld = s.resid_ld;
@@ -656,6 +665,30 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   int tile = -1;
   const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
   ex->launches++;
+  static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
+  if (fuse_stats && s.want_stats && mfma_ok && conv_tile_fuses_stats(tile) && a.ksplit == 1 && a.tb_log2 == 0 &&
+      (a.Cout & 3) == 0 &&
+      a.out_ld == a.Cout && (!a.resid || (a.resid_ld & 3) == 0)) {
+    StatInfo& si = ex->stats[s.out.id];
+    si.nchunk = a.tiles_x * a.tiles_y * conv_tile_wm(tile);
+    si.part = ws_alloc(ex, (size_t)a.B * si.nchunk * a.Cout * 2 * sizeof(float));
+    si.planned = true;
+    si.f32 = true;
+    a.stat_part = (float*)si.part;
+  }
+  {  // diagnostics: DSX_STAMP_OP=<conv ordinal>[,<block>] -> in-kernel phase stamps of that launch
+    static const char* se = getenv("DSX_STAMP_OP");
+    if (se && mfma_ok) {
+      const int want = atoi(se);
+      const char* comma = strchr(se, ',');
+      if (ex->conv_ordinal == want) {
+        a.stamp = (unsigned long long*)ws_alloc(ex, 128 * 8);
+        a.stamp_block = comma ? atoi(comma + 1) : 0;
+        ex->stamp_buf = a.stamp;
+      }
+    }
+    ex->conv_ordinal++;
+  }
   float* slab = nullptr;
   if (mfma_ok && a.ksplit > 1) {
     slab = (float*)ws_alloc(ex, (size_t)a.ksplit * a.slab_stride * sizeof(float));
@@ -709,11 +742,12 @@ static void plan_stats(dsx_exec* ex, const Tensor& t) {
   nchunk = std::min(nchunk, std::max(1, HW / 16));
   nchunk = std::min(nchunk, 64);
   si.nchunk = nchunk;
-  si.part = (double*)ws_alloc(ex, (size_t)ex->B * nchunk * t.C * 2 * sizeof(double));
+  si.part = ws_alloc(ex, (size_t)ex->B * nchunk * t.C * 2 * sizeof(double));
   si.planned = true;
+  si.f32 = false;
   ex->launches++;
   if (ex->sizing) return;
-  const float* x = t.p; double* part = si.part;
+  const float* x = t.p; double* part = (double*)si.part;
   const int B = ex->B, C = t.C;
   add_op(ex, DSX_OP_GN_STATS, fmt("gn_stats C=%d @%dx%d", C, t.H, t.W), 0.0, 4.0 * B * HW * C,
          [=](hipStream_t st) { return launch_chan_stats(x, B, HW, C, nchunk, part, st); });
@@ -730,8 +764,10 @@ static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* 
   if (ex->sizing) return;
   GnFinArgs a{};
   a.part0 = ex->stats[t0.id].part; a.C0 = t0.C; a.nchunk0 = ex->stats[t0.id].nchunk;
+  a.f32_0 = ex->stats[t0.id].f32 ? 1 : 0;
   a.part1 = t1 ? ex->stats[t1->id].part : nullptr; a.C1 = t1 ? t1->C : 0;
   a.nchunk1 = t1 ? ex->stats[t1->id].nchunk : 0;
+  a.f32_1 = (t1 && ex->stats[t1->id].f32) ? 1 : 0;
   a.B = ex->B; a.groups = ex->m->cfg.norm_groups; a.count = (double)t0.H * t0.W;
   a.gamma = g.gamma; a.beta = g.beta; a.eps = 1e-5f;
   a.scale = *scale; a.shift = *shift;
@@ -749,7 +785,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   c1.w = &md.conv1; c1.x0 = x0; if (x1) c1.x1 = *x1;
   c1.gn_scale = s1; c1.gn_shift = h1; c1.swish = true;
   if (md.film_off >= 0 && !ex->sizing) { c1.film = ex->film + md.film_off; c1.film_bs = ex->m->F; }
-  c1.out = h;
+  c1.out = h; c1.want_stats = true;
   if ((rc = plan_conv(ex, c1))) return rc;
   plan_gn(ex, md.gn2, h, nullptr, &s2, &h2);
   Tensor r;
@@ -764,7 +800,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   Tensor o = new_tensor(ex, md.cout, H, W);
   ConvSpec c2{};
   c2.w = &md.conv2; c2.x0 = h; c2.gn_scale = s2; c2.gn_shift = h2; c2.swish = true;
-  c2.resid = r.p; c2.resid_ld = md.cout; c2.out = o;
+  c2.resid = r.p; c2.resid_ld = md.cout; c2.out = o; c2.want_stats = true;
   if ((rc = plan_conv(ex, c2))) return rc;
   if (!md.attn) { y = o; return DSX_OK; }
   // SelfAttention (unet.py:113-142)
@@ -798,7 +834,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   }
   Tensor o2 = new_tensor(ex, C, H, W);
   ConvSpec co{};
-  co.w = &md.out; co.x0 = av; co.resid = o.p; co.resid_ld = C; co.out = o2;
+  co.w = &md.out; co.x0 = av; co.resid = o.p; co.resid_ld = C; co.out = o2; co.want_stats = true;
   if ((rc = plan_conv(ex, co))) return rc;
   y = o2;
   return DSX_OK;
@@ -808,6 +844,7 @@ static int build_plan(dsx_exec* ex) {
   dsx_model* m = ex->m;
   ex->ws_used = 0;
   ex->ops.clear();
+  ex->conv_ordinal = 0;
   ex->op_info.clear();
   ex->stats.clear();
   ex->launches = 0;
@@ -827,20 +864,20 @@ static int build_plan(dsx_exec* ex) {
       ConvSpec c{};
       c.w = &md.conv;
       if (ex->cond_c) { c.x0 = ex->in_cond; c.x1 = ex->in_x; } else c.x0 = ex->in_x;
-      c.out = o;
+      c.out = o; c.want_stats = true;
       if ((rc = plan_conv(ex, c))) return rc;
       x = o; feats.push_back(x);
     } else if (md.kind == 2) {
       if ((x.H & 1) || (x.W & 1)) return fail(DSX_ERR_INVALID, "H and W must be divisible by 2^(levels-1)");
       Tensor o = new_tensor(ex, md.cout, x.H / 2, x.W / 2);
       ConvSpec c{};
-      c.w = &md.conv; c.x0 = x; c.stride = 2; c.out = o;
+      c.w = &md.conv; c.x0 = x; c.stride = 2; c.out = o; c.want_stats = true;
       if ((rc = plan_conv(ex, c))) return rc;
       x = o; feats.push_back(x);
     } else if (md.kind == 3) {
       Tensor o = new_tensor(ex, md.cout, x.H * 2, x.W * 2);
       ConvSpec c{};
-      c.w = &md.conv; c.x0 = x; c.up = true; c.out = o;
+      c.w = &md.conv; c.x0 = x; c.up = true; c.out = o; c.want_stats = true;
       if ((rc = plan_conv(ex, c))) return rc;
       x = o;
     } else if (md.kind == 1) {
@@ -919,6 +956,16 @@ extern "C" int dsx_exec_op_info(const dsx_exec* ex, int i, char* desc, int cap, 
   if (bytes) *bytes = o.bytes;
   return DSX_OK;
 }
+// diagnostics: copy the 128 in-kernel stamps of the launch chosen with DSX_STAMP_OP (zeros if none)
+extern "C" int dsx_exec_read_stamps(dsx_exec* ex, unsigned long long* out128) {
+  if (!ex || !out128) return fail(DSX_ERR_INVALID, "null argument");
+  memset(out128, 0, 128 * 8);
+  if (!ex->stamp_buf) return DSX_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out128, ex->stamp_buf, 128 * 8, hipMemcpyDeviceToHost));
+  return DSX_OK;
+}
+
 // Eager, event-timed replay of the UNet plan on `stream` (inputs: whatever the
 // buffers hold).  ms_per_op[i] = mean over `iters` of the hipEvent time around launch i.
 extern "C" int dsx_exec_profile(dsx_exec* ex, int iters, float* ms_per_op, void* stream) {

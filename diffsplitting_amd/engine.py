@@ -126,10 +126,12 @@ class UNetEngine:
         return float(lib.dsx_model_flops(self._h, int(H), int(W)))
 
     # ---- execution ---------------------------------------------------------
-    def executor(self, B, H, W, cond_channels=0):
+    def executor(self, B, H, W, cond_channels=0, slot=0):
+        """One executor (plan + workspace) per geometry and ``slot``; concurrent loops on
+        different streams must use different slots (an executor's calls are not concurrent)."""
         if self._finalized_dtype is None:
             raise DsxError("finalize() must precede execution")
-        key = (int(B), int(H), int(W), int(cond_channels))
+        key = (int(B), int(H), int(W), int(cond_channels), int(slot))
         ex = self._execs.get(key)
         if ex is None:
             ex = C.c_void_p()
@@ -161,14 +163,14 @@ class UNetEngine:
         return y
 
     def sample_loop(self, table, x_init, cond=None, noise=None, seed=0, snapshot_steps=(),
-                    use_graph=True, stream=None):
+                    use_graph=True, stream=None, slot=0):
         """Runs ``table`` (a ``StepTableHost``) from ``x_init`` (B,C,H,W) in place.
         Returns (final_state, snapshots) with snapshots (n_snap,B,C,H,W) or None.
         Asynchronous on the current (or given) stream."""
         x = x_init.contiguous()
         B, Cx, H, W = x.shape
         cc = 0 if cond is None else cond.shape[1]
-        ex = self.executor(B, H, W, cc)
+        ex = self.executor(B, H, W, cc, slot)
         if cond is not None:
             cond = cond.to(dtype=torch.float32).contiguous()
         if noise is not None:

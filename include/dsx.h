@@ -110,6 +110,8 @@ int dsx_exec_num_ops(const dsx_exec* ex);
 int dsx_exec_op_info(const dsx_exec* ex, int index, char* desc_buf, int desc_cap, int* kind,
                      double* flops, double* bytes);
 int dsx_exec_profile(dsx_exec* ex, int iters, float* ms_per_op, void* stream);
+/* diagnostics: in-kernel phase stamps (s_memtime) of the conv launch selected by DSX_STAMP_OP */
+int dsx_exec_read_stamps(dsx_exec* ex, unsigned long long* out128);
 
 /* One UNet forward: replaces denoise_fn(x, t)
  * (sr3 unet.py:235-259 / ddpm unet.py:220-243).
