@@ -68,6 +68,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
       a.stamp[(i)] = __builtin_amdgcn_s_memtime();                                          \
   } while (0)
 
+#define DSX_STAMP_T(i, cond)                                                               \
+  do {                                                                                      \
+    if (a.stamp != nullptr && blockIdx.x == (unsigned)a.stamp_block && (cond) && (i) < 128)  \
+      a.stamp[(i)] = __builtin_amdgcn_s_memtime();                                          \
+  } while (0)
+
 template <typename DT> struct Chunk;
 template <> struct Chunk<float> { static constexpr int KC = 16; };
 template <> struct Chunk<__bf16> { static constexpr int KC = 32; };
@@ -83,7 +89,7 @@ template <> struct Chunk<__bf16> { static constexpr int KC = 32; };
 // code has no predicates.  LDS image: pixel stride PIXB, row pitch `a.lds_row` chosen by the
 // host so that ds_read_b128 of a 32-row fragment is bank-conflict-free (see conv_lds_row).
 template <typename DT, int MB, int WM, int WN, int KS, int S, int CPG, int D, int MAX_IT>
-__global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
+__global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1)))) void k_conv_mfma(const ConvArgs a) {
   constexpr int KC = Chunk<DT>::KC;
   constexpr int UPP = KC / 4;                 // 4-channel staging units per pixel per chunk
   constexpr int UPG = UPP * CPG;              // ... per group
@@ -460,6 +466,465 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvArgs a) {
   DSX_STAMP(6);
 }
 
+// ===========================================================================================
+// Warp-specialised, persistent variant (stride 1, sources aligned to the channel group).
+//
+// Why: inside one wave the activation stream (HBM, ~3 us under load) and the weight-fragment stream
+// (L2, ~0.6 us) share ONE in-order vmcnt queue, so neither can be prefetched deeper than the other
+// allows, and every phase of k_conv_mfma (load wait, GN+Swish VALU, MFMA, epilogue) ends up serialised.
+// Here a workgroup is 8 waves:
+//   waves 4-7  LOADERS : LDS-DMA (buffer_load ... lds, no VGPRs) of the raw fp32 halo patch P groups
+//                        ahead into a ring, then GroupNorm affine + Swish + convert and the MFMA image
+//                        of the NEXT group; their vmcnt only ever counts activation DMAs.
+//   waves 0-3  COMPUTE : weight-fragment ring + MFMA on the CURRENT group's image, epilogue + fused
+//                        statistics at tile ends; their vmcnt only counts weight / epilogue loads.
+// Both pipes of a SIMD stay busy (one loader + one compute wave per SIMD: VALU beside MFMA), the
+// workgroup is persistent over M tiles of one N tile (the weight stream stays in L2, the pipelines run
+// on across tile boundaries, per-workgroup setup is paid once), and there is one raw s_barrier per
+// group (never __syncthreads: its vmcnt(0) would drain the DMA ring).
+// ===========================================================================================
+// LDS accesses of the loader waves go through inline asm: for a ds_read that may alias an LDS-DMA
+// destination hipcc would insert s_waitcnt vmcnt(0) and drain the whole DMA ring; ordering is done by
+// the counted vmcnt waits (wait_item) instead.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+static __device__ __forceinline__ f32x4_t lds_read_b128_asm(unsigned addr) {
+  f32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+static __device__ __forceinline__ void lds_write_b64_asm(unsigned addr, u32x2_t w) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(w) : "memory");
+}
+static __device__ __forceinline__ void lds_write_b128_asm(unsigned addr, f32x4_t w) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w) : "memory");
+}
+
+static __device__ __forceinline__ void ws_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: own LDS writes visible, DMAs stay in flight
+  __builtin_amdgcn_s_barrier();
+}
+template <int N> static __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0F70);  // vmcnt(N) only
+}
+
+template <typename DT, int MB, int WM, int WN, int KS, int CPG, int D, int NIT, int P, int LW>
+__global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) {
+  constexpr int LT = 64 * LW;                   // loader threads
+  constexpr int S = 1;
+  constexpr int KC = Chunk<DT>::KC;
+  constexpr int UPP = KC / 4;
+  constexpr int UPG = UPP * CPG;
+  constexpr int UPG_LOG2 = UPG == 16 ? 4 : (UPG == 8 ? 3 : 2);
+  constexpr int UB = 4 * (int)sizeof(DT);
+  constexpr int PIXB = 64 * CPG + 16;
+  constexpr int TAPS = KS * KS;
+  constexpr int PAD = KS / 2;
+  constexpr int NSTEP = CPG * TAPS * 2;
+  constexpr bool IS_BF16 = sizeof(DT) == 2;
+  constexpr int RAWB = NIT * LT * 16;           // one raw ring slot
+  constexpr int NSLOT = P + 1;
+  static_assert(NSTEP % D == 0, "ring depth must divide the steps per group");
+  static_assert(WM * WN == 4 && P * NIT < 64, "4 compute waves; vmcnt is 6 bits");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = loader ? wave8 - 4 : wave8;  // index inside the role
+  const int ltid = loader ? tid - 256 : tid;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int TW = 1 << a.tw_log2, TH = 1 << a.th_log2;
+  const int PW = (TW - 1) * S + KS;
+  const int PH = (TH - 1) * S + KS;
+  const int PPI = PH * PW;
+  const int PP = PPI << a.tb_log2;
+  const int RB = a.lds_row;
+  const int BUFB = (PH << a.tb_log2) * RB;
+  // [image 0][image 1][GroupNorm scale/shift of two tiles' images][raw ring]
+  const int C = a.C0 + a.C1;
+  const int AFFB = a.has_gn ? ((2 * C * 4 + 15) & ~15) : 0;     // bytes of one tile's {scale[C], shift[C]}
+  float* const aff_base = (float*)(lds + 2 * BUFB);
+  unsigned char* const raw_base = lds + 2 * BUFB + 2 * AFFB;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;  // LDS byte address of lds[0]
+  const int Hi = a.up ? a.Hs * 2 : a.Hs;
+  const int Wi = a.up ? a.Ws * 2 : a.Ws;
+  const int G = a.kchunks / CPG;                // channel groups per tile (no split-K here; host: G >= 2, TB == 1)
+
+  // persistent work list: this workgroup owns N tile `nt` and M tiles p, p+wpn, ...
+  // XCD-aware: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the L2 they
+  // share), so an N tile's workgroups are pinned to as few XCDs as possible and every L2 only
+  // streams its own slice of the weights (placement affects speed only, never results).
+  const int wpn = a.ws_wg_per_n;
+  int nt, p0;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, k = bid >> 3, NT = a.n_tiles;
+    if (NT <= 8 && (8 % NT) == 0 && (wpn % (8 / NT)) == 0) {
+      nt = xcd % NT;
+      p0 = k * (8 / NT) + xcd / NT;
+    } else if ((NT & 7) == 0) {
+      const int per = NT >> 3;
+      nt = xcd + 8 * (k % per);
+      p0 = k / per;
+    } else {
+      nt = bid / wpn;
+      p0 = bid - nt * wpn;
+    }
+  }
+  const int ntile = (a.m_tiles - p0 + wpn - 1) / wpn;
+  const int total = ntile * G;                  // (tile, group) items, in order
+
+  auto tile_coords = [&](int ti, int& oy0, int& ox0, int& b0) {
+    const int mt = p0 + ti * wpn;
+    const int txi = mt % a.tiles_x;
+    const int tyi = (mt / a.tiles_x) % a.tiles_y;
+    const int bg = mt / (a.tiles_x * a.tiles_y);
+    oy0 = tyi << a.th_log2; ox0 = txi << a.tw_log2; b0 = bg << a.tb_log2;
+  };
+
+  if (loader) {
+    // ======================================================================= LOADER WAVES
+    const int nunits = PP << UPG_LOG2;
+    const int cvg = ltid & (UPG - 1);
+    int loff[NIT];            // LDS image offset of each unit (tile-invariant), -1: no such unit
+    int dpy_, dpx_;
+    int tb0, py0, px0;        // (tb,py,px) of this thread's first unit
+    {
+      constexpr int PSTEP = LT >> UPG_LOG2;
+      const int pix0 = ltid >> UPG_LOG2;
+      tb0 = pix0 / PPI;
+      const int rem = pix0 - tb0 * PPI;
+      py0 = rem / PW;
+      px0 = rem - py0 * PW;
+      dpy_ = PSTEP / PW; dpx_ = PSTEP - dpy_ * PW;
+      int tb = tb0, py = py0, px = px0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        loff[it] = (ltid + it * LT < nunits) ? (tb * PH + py) * RB + px * PIXB + cvg * UB : -1;
+        px += dpx_; py += dpy_;
+        if (px >= PW) { px -= PW; py += 1; }
+        while (py >= PH) { py -= PH; tb += 1; }
+      }
+    }
+    // source pixel index per unit for tile `ti` (-1: zero padding / outside the batch / no unit)
+    auto make_plan = [&](int ti, int* soff, int& b0_out) {
+      int oy0, ox0, b0;
+      tile_coords(ti, oy0, ox0, b0);
+      b0_out = b0;
+      const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+      int tb = tb0, py = py0, px = px0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        int so = -1;
+        const int b = b0 + tb;
+        if (loff[it] >= 0) {
+          const int iy = iy0 + py, ix = ix0 + px;
+          if (b < a.B && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
+            const int sy = a.up ? (iy >> 1) : iy;
+            const int sx = a.up ? (ix >> 1) : ix;
+            so = (b * a.Hs + sy) * a.Ws + sx;
+          }
+        }
+        soff[it] = so;
+        px += dpx_; py += dpy_;
+        if (px >= PW) { px -= PW; py += 1; }
+        while (py >= PH) { py -= PH; tb += 1; }
+      }
+    };
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.src0, 0, (int)min((long long)a.B * a.Hs * a.Ws * a.C0 * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.src1 ? a.src1 : a.src0), 0,
+        a.src1 ? (int)min((long long)a.B * a.Hs * a.Ws * a.C1 * 4, 0x7fffffffLL) : 0, 0x00020000);
+
+    int soffI[NIT], soffC[NIT];
+    int b0I = 0, b0C = 0;
+    int tiI = 0, gI = 0;      // next item to issue
+    int tiC = 0, gC = 0;      // next item to consume
+    make_plan(0, soffI, b0I);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) soffC[it] = soffI[it];
+    b0C = b0I;
+
+    // DMA the raw patch of item (tiI, gI) into ring slot `slot`; every wave issues exactly NIT instructions
+    auto issue = [&](int slot) {
+      const int c = gI * (CPG * KC) + cvg * 4;
+      const bool first = gI * (CPG * KC) < a.C0;            // uniform: a group never straddles the sources
+      const int cs = first ? a.C0 : a.C1;
+      const unsigned coff = c < C ? (unsigned)((first ? c : c - a.C0) * 4) : 0x80000000u;
+      unsigned char* dst = raw_base + slot * RAWB + wave * 1024;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const unsigned vo = soffI[it] >= 0 ? (unsigned)soffI[it] * (unsigned)(cs * 4) + coff : 0x80000000u;
+        auto ldst = (__attribute__((address_space(3))) void*)(dst + it * (LT * 16));
+        if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, ldst, 16, vo, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, ldst, 16, vo, 0, 0, 0);
+      }
+      if (++gI == G) { gI = 0; ++tiI; if (tiI < ntile) make_plan(tiI, soffI, b0I); }
+    };
+    // raw slot -> GroupNorm affine + Swish -> MFMA image `buf` for item (tiC, gC)
+    auto consume = [&](int slot, int buf) {
+      const int c = gC * (CPG * KC) + cvg * 4;
+      const unsigned src = lds0 + 2 * BUFB + 2 * AFFB + slot * RAWB + ltid * 16;
+      const unsigned dst = lds0 + buf * BUFB;
+      const bool has_gn = a.gn_scale != nullptr && c < C;
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (has_gn) {
+        // the compute waves parked this tile's scale/shift in LDS (an ordinary global load here would
+        // make the compiler wait vmcnt(0) and drain the DMA ring)
+        const unsigned af = lds0 + 2 * BUFB + (tiC & 1) * AFFB;
+        const f32x4_t s4 = lds_read_b128_asm(af + c * 4);
+        const f32x4_t h4 = lds_read_b128_asm(af + (C + c) * 4);
+        sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+        sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+      }
+      f32x4_t rv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)   // all raw reads in flight, one wait
+        asm volatile("ds_read_b128 %0, %1" : "=v"(rv[it]) : "v"(src + it * (LT * 16)) : "memory");
+      if constexpr (NIT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0])::"memory");
+      else if constexpr (NIT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1])::"memory");
+      else if constexpr (NIT == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2])::"memory");
+      else if constexpr (NIT == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3])::"memory");
+      else if constexpr (NIT == 5)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4])::"memory");
+      else if constexpr (NIT == 6)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5])::"memory");
+      else if constexpr (NIT == 7)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7])::"memory");
+      static_assert(NIT <= 8, "loader units per thread");
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (loff[it] >= 0) {
+          float4 v = make_float4(rv[it].x, rv[it].y, rv[it].z, rv[it].w);
+          if (soffC[it] >= 0 && c < C) {
+            if (has_gn) {
+              v.x = v.x * sc[0] + sh[0];
+              v.y = v.y * sc[1] + sh[1];
+              v.z = v.z * sc[2] + sh[2];
+              v.w = v.w * sc[3] + sh[3];
+            }
+            if (a.swish) {
+              v.x = swish_f(v.x); v.y = swish_f(v.y); v.z = swish_f(v.z); v.w = swish_f(v.w);
+            }
+          } else {
+            v = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          const unsigned p = dst + loff[it];
+          if constexpr (IS_BF16) {
+            u32x2_t w;
+            w.x = pack_bf16x2(v.x, v.y);
+            w.y = pack_bf16x2(v.z, v.w);
+            lds_write_b64_asm(p, w);
+          } else {
+            f32x4_t w = {v.x, v.y, v.z, v.w};
+            lds_write_b128_asm(p, w);
+          }
+        }
+      }
+      if (++gC == G) { gC = 0; ++tiC; if (tiC < ntile) make_plan(tiC, soffC, b0C); }
+    };
+    // wait until item w's DMAs have landed: only the k = min(P, total-1-w) younger groups may stay in flight
+    auto wait_item = [&](int w) {
+      const int k = min(P, total - 1 - w);
+      if (k >= P) wait_vmcnt<P * NIT>();
+      else if (P > 1 && k == P - 1) wait_vmcnt<(P > 1 ? (P - 1) * NIT : 0)>();
+      else if (P > 2 && k == P - 2) wait_vmcnt<(P > 2 ? (P - 2) * NIT : 0)>();
+      else if (P > 3 && k == P - 3) wait_vmcnt<(P > 3 ? (P - 3) * NIT : 0)>();
+      else wait_vmcnt<0>();
+    };
+
+    int issued = 0;
+    for (; issued < NSLOT && issued < total; ++issued) issue(issued % NSLOT);
+    ws_barrier();                       // scale/shift of tiles 0 and 1 are in LDS
+    wait_item(0);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(0, 0);
+    ws_barrier();
+    DSX_STAMP_T(64, tid == 256);
+    for (int v = 0; v < total; ++v) {
+      // slot of item v (its image was built one iteration ago) is free again: reuse it for item v+NSLOT
+      if (issued < total) { issue(issued % NSLOT); ++issued; }
+      DSX_STAMP_T(65 + 4 * v, tid == 256 && v < 15);
+      if (v + 1 < total) {
+        wait_item(v + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        DSX_STAMP_T(66 + 4 * v, tid == 256 && v < 15);
+        consume((v + 1) % NSLOT, (v + 1) & 1);
+      }
+      DSX_STAMP_T(67 + 4 * v, tid == 256 && v < 15);
+      ws_barrier();
+      DSX_STAMP_T(68 + 4 * v, tid == 256 && v < 15);
+    }
+    return;
+  }
+
+  // ========================================================================= COMPUTE WAVES
+  const int wm = wave / WN, wn = wave % WN;
+  int abase[MB][KS];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = (wm * MB + mb) * 32 + li;
+    const int tx = m & (TW - 1);
+    const int ty = (m >> a.tw_log2) & (TH - 1);
+    const int tb = m >> (a.tw_log2 + a.th_log2);
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+      abase[mb][dy] = (tb * PH + ty * S + dy) * RB + tx * S * PIXB + lh * 16;
+  }
+  int blk = nt * WN + wn;
+  if (blk >= a.nblocks) blk = a.nblocks - 1;
+  const long long wblock = (long long)G * (NSTEP * 1024);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const unsigned char*)a.wpack + (size_t)blk * wblock), 0, (int)wblock, 0x00020000);
+  const int wlane = lane * 16;
+  const int qtot = G * NSTEP;                   // the stream restarts at every tile (same N block)
+  int qn = 0;                                   // next step to prefetch (wraps)
+  auto load_b = [&]() -> uint4 {
+    const uint4 r = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, qn * 1024, 0));
+    if (++qn == qtot) qn = 0;
+    return r;
+  };
+  uint4 bq[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) bq[j] = load_b();
+
+  f32x16 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+
+  constexpr bool STATS = MB <= 2;
+  const bool do_stats = STATS && a.stat_part != nullptr;
+  const int nbase = (nt * WN + wn) * 32 + 4 * lh;
+
+  // GroupNorm scale/shift of tile `t`'s image -> LDS (parity slot), for the loader waves
+  auto load_aff = [&](int t) {
+    if (a.gn_scale == nullptr || t >= ntile) return;
+    int oy0, ox0, b0;
+    tile_coords(t, oy0, ox0, b0);
+    float* dst = aff_base + (size_t)(t & 1) * (AFFB / 4);
+    for (int i = tid * 4; i < C; i += 1024) {
+      *(float4*)(dst + i) = *(const float4*)(a.gn_scale + (size_t)b0 * C + i);
+      *(float4*)(dst + C + i) = *(const float4*)(a.gn_shift + (size_t)b0 * C + i);
+    }
+  };
+  load_aff(0);
+  load_aff(1);
+  ws_barrier();   // scale/shift visible to the loaders
+  ws_barrier();   // image of item 0 is ready
+  DSX_STAMP_T(0, tid == 0);
+  int g = 0, ti = 0;
+  for (int v = 0; v < total; ++v) {
+    const unsigned char* abuf = lds + (v & 1) * BUFB;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const uint4 bcur = bq[s % D];
+      bq[s % D] = load_b();
+      constexpr int kTapSteps = TAPS * 2;
+      const int cg = s / kTapSteps, tap = (s >> 1) % TAPS, fs = s & 1;
+      const int dy = tap / KS, dx = tap % KS;
+      const int imm = dx * PIXB + cg * 64 + fs * 32;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const uint4 av = *(const uint4*)(abuf + abase[mb][dy] + imm);
+        if constexpr (IS_BF16) {
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur),
+                                                            __builtin_bit_cast(bf16x8, av), acc[mb], 0, 0, 0);
+        } else {
+          const float4 af = __builtin_bit_cast(float4, av);
+          const float4 bf = __builtin_bit_cast(float4, bcur);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af.z, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc[mb], 0, 0, 0);
+        }
+      }
+    }
+    DSX_STAMP_T(1 + 3 * v, tid == 0 && v < 20);
+    ws_barrier();   // the loaders may now overwrite this image; the next one is complete
+    DSX_STAMP_T(2 + 3 * v, tid == 0 && v < 20);
+    if (++g < G) continue;
+    g = 0;
+    load_aff(ti + 2);   // tile ti+1's is already there; slot parity of ti+2 == ti, whose use has ended
+
+    // ---- tile finished: epilogue (+ fused statistics), same layout as k_conv_mfma
+    int oy0, ox0, b0;
+    tile_coords(ti, oy0, ox0, b0);
+    const int mt = p0 + ti * wpn;
+    ++ti;
+    const bool vec = (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (!a.resid || (a.resid_ld & 3) == 0);
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = (wm * MB + mb) * 32 + li;
+      const int tx = m & (TW - 1);
+      const int ty = (m >> a.tw_log2) & (TH - 1);
+      const int b = b0 + (m >> (a.tw_log2 + a.th_log2));
+      if (b < a.B) {
+        const size_t opix = ((size_t)b * a.Ho + (oy0 + ty)) * a.Wo + (ox0 + tx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = nbase + 8 * j;
+          if (n >= a.Cout) continue;
+          float x[4] = {acc[mb][4 * j], acc[mb][4 * j + 1], acc[mb][4 * j + 2], acc[mb][4 * j + 3]};
+          if (vec) {
+            if (a.bias) { const float4 t = *(const float4*)(a.bias + n); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
+            if (a.film) { const float4 t = *(const float4*)(a.film + (size_t)b * a.film_bs + n); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
+            if (a.resid) { const float4 t = *(const float4*)(a.resid + opix * a.resid_ld + n); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
+            *(float4*)(a.out + opix * a.out_ld + n) = make_float4(x[0], x[1], x[2], x[3]);
+            if (do_stats) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { s1[4 * j + k] += x[k]; s2[4 * j + k] += x[k] * x[k]; }
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (n + k >= a.Cout) break;
+              float y = x[k];
+              if (a.bias) y += a.bias[n + k];
+              if (a.film) y += a.film[(size_t)b * a.film_bs + n + k];
+              if (a.resid) y += a.resid[opix * a.resid_ld + n + k];
+              a.out[opix * a.out_ld + n + k] = y;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+    }
+    if (do_stats) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+      float w1 = s1[0], w2 = s2[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) { if ((li & 15) == r) { w1 = s1[r]; w2 = s2[r]; } }
+      w1 += __shfl_xor(w1, 16, 64);
+      w2 += __shfl_xor(w2, 16, 64);
+      const int per_img = a.tiles_x * a.tiles_y;
+      const int chunk = (mt % per_img) * WM + wm;
+      const int nch = per_img * WM;
+      const int n = (nt * WN + wn) * 32 + (li & 3) + 8 * (li >> 2) + 4 * lh;
+      if (li < 16 && n < a.Cout) {
+        float* pp = a.stat_part + (((size_t)b0 * nch + chunk) * a.Cout + n) * 2;
+        pp[0] = w1; pp[1] = w2;
+      }
+    }
+    DSX_STAMP_T(3 + 3 * v, tid == 0 && v < 20);
+  }
+}
+
 // ------------------------------------------------------------------ dispatch
 struct TileCfg { int MB, WM, WN; };
 static constexpr TileCfg kTiles[TILE_COUNT] = {
@@ -565,6 +1030,69 @@ hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& 
                     : launch_dt<float>(tile, ks, stride, &a, lds, st);
 }
 
+// ---- warp-specialised variant: per (dtype, tile, ks) constants
+static constexpr bool ws_tile_ok(int tile) {
+  return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;
+}
+static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activations in flight beyond the current one
+  const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
+  return bm == 64 ? 4 : (ks == 1 ? 2 : 3);
+}
+static constexpr int kWsLoaderWaves = 8;
+static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units per loader thread per group
+  const int upg = (dtype == 1 ? 8 : 4) * conv_cpg(ks);
+  return (max_px(tile, ks, 1) * upg + kWsLoaderWaves * 64 - 1) / (kWsLoaderWaves * 64);
+}
+size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
+  if (!ws_tile_ok(tile) || !(ks == 1 || ks == 3)) return 0;
+  if (conv_lds_bytes(dtype, tile, ks, 1, a) == 0) return 0;
+  const int ph = ((1 << a.th_log2) - 1) + ks;
+  const size_t bufb = (size_t)(ph << a.tb_log2) * a.lds_row;
+  const size_t rawb = (size_t)ws_nit(dtype, tile, ks) * (kWsLoaderWaves * 64 * 16);
+  const size_t affb = a.has_gn ? (((size_t)2 * (a.C0 + a.C1) * 4 + 15) & ~(size_t)15) : 0;  // never keyed on a pointer
+  const size_t total = 2 * bufb + 2 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb;
+  if (a.tb_log2 != 0 || a.kchunks / conv_cpg(ks) < 2) return 0;   // one image per tile, >= 2 channel groups
+  return total <= 160 * 1024 ? total : 0;
+}
+
+template <typename DT, int TILE, int KS>
+static hipError_t launch_ws_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
+  if constexpr (!ws_tile_ok(TILE)) {
+    return hipErrorInvalidValue;
+  } else {
+    constexpr TileCfg t = kTiles[TILE];
+    constexpr int CPG = conv_cpg(KS);
+    constexpr int D = KS == 1 ? 4 : 18;   // full-group weight ring (3 waves/SIMD: 168 registers per thread)
+    constexpr int NIT = ws_nit(sizeof(DT) == 2 ? 1 : 0, TILE, KS);
+    constexpr int P = ws_depth(TILE, KS);
+    auto kern = k_conv_ws<DT, t.MB, t.WM, t.WN, KS, CPG, D, NIT, P, kWsLoaderWaves>;
+    if (!ap)
+      return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const ConvArgs& a = *ap;
+    dim3 grid((unsigned)(a.n_tiles * a.ws_wg_per_n));
+    hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * kWsLoaderWaves), lds, st, a);
+    return hipGetLastError();
+  }
+}
+template <typename DT>
+static hipError_t launch_ws_dt(int tile, int ks, const ConvArgs* a, size_t lds, hipStream_t st) {
+#define DSX_WS_CASE(T) \
+  case T: return ks == 3 ? launch_ws_one<DT, T, 3>(a, lds, st) : launch_ws_one<DT, T, 1>(a, lds, st);
+  switch (tile) {
+    DSX_WS_CASE(TILE_128x128)
+    DSX_WS_CASE(TILE_64x128)
+    DSX_WS_CASE(TILE_128x64)
+    DSX_WS_CASE(TILE_64x64)
+    default: return hipErrorInvalidValue;
+  }
+#undef DSX_WS_CASE
+}
+hipError_t launch_conv_ws(int dtype, int tile, int ks, const ConvArgs& a, hipStream_t st) {
+  const size_t lds = conv_ws_lds_bytes(dtype, tile, ks, a);
+  if (lds == 0 || a.ksplit != 1 || a.ws_wg_per_n < 1 || a.stage_mode != 0) return hipErrorInvalidValue;
+  return dtype == 1 ? launch_ws_dt<__bf16>(tile, ks, &a, lds, st) : launch_ws_dt<float>(tile, ks, &a, lds, st);
+}
+
 hipError_t conv_init() {
   static bool done = false;
   if (done) return hipSuccess;
@@ -576,6 +1104,11 @@ hipError_t conv_init() {
           hipError_t e = dtype == 1 ? launch_dt<__bf16>(tile, ks, stride, nullptr, 0, nullptr)
                                     : launch_dt<float>(tile, ks, stride, nullptr, 0, nullptr);
           if (e != hipSuccess) return e;
+          if (stride == 1 && ws_tile_ok(tile)) {
+            e = dtype == 1 ? launch_ws_dt<__bf16>(tile, ks, nullptr, 0, nullptr)
+                           : launch_ws_dt<float>(tile, ks, nullptr, 0, nullptr);
+            if (e != hipSuccess) return e;
+          }
         }
   done = true;
   return hipSuccess;

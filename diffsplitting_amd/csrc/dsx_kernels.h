@@ -22,6 +22,7 @@ struct ConvArgs {
   int Ho, Wo;             // output spatial size
   const float* gn_scale;  // [B][C0+C1] or nullptr:  v = x*scale + shift
   const float* gn_shift;
+  int has_gn;             // GroupNorm affine fused (== gn_scale != nullptr once the workspace exists)
   int swish;              // v = v*sigmoid(v) after the affine
   int stage_mode;         // 0: sources aligned to the channel group (buffer loads); 1: float4 loads with
                           // per-lane source select; 2: channel counts not multiples of 4 (per-element loads)
@@ -39,6 +40,7 @@ struct ConvArgs {
   int tw_log2, th_log2, tb_log2;  // output tile = TB images x TH x TW pixels
   int tiles_x, tiles_y, m_tiles, n_tiles;
   int lds_row;            // LDS bytes per patch row (conv_lds_row)
+  int ws_wg_per_n;        // warp-specialised kernel: persistent workgroups per N tile (0: k_conv_mfma)
   float* stat_part;       // fused GroupNorm partials [B][tiles_x*tiles_y*WM][Cout][2] (fp32) or nullptr
   unsigned long long* stamp;  // diagnostic s_memtime stamps of workgroup `stamp_block` (or nullptr)
   int stamp_block;
@@ -60,6 +62,9 @@ int conv_lds_row(int ks, int stride, int tw_log2);
 // LDS bytes needed by a launch; 0 if the geometry is not supported by `tile`
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a);
 hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& a, hipStream_t st);
+// warp-specialised persistent variant (stride 1, stage_mode 0, no split-K); 0 bytes = not applicable
+size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a);
+hipError_t launch_conv_ws(int dtype, int tile, int ks, const ConvArgs& a, hipStream_t st);
 // one-time function attributes (dynamic LDS limit); call outside any stream capture
 hipError_t conv_init();
 

@@ -492,6 +492,7 @@ struct dsx_exec {
   std::vector<std::function<hipError_t(hipStream_t)>> ops;  // the UNet forward
   std::vector<OpInfo> op_info;                               // parallel to ops
   int conv_ordinal = 0;
+  bool overflow = false;
   unsigned long long* stamp_buf = nullptr;
   std::vector<StatInfo> stats;
   // fixed buffers
@@ -533,6 +534,7 @@ static char* ws_alloc(dsx_exec* ex, size_t bytes) {
   size_t off = (ex->ws_used + 255) & ~(size_t)255;
   ex->ws_used = off + bytes;
   if (ex->sizing) return nullptr;
+  if (ex->ws_used > ex->ws_bytes) ex->overflow = true;   // sizing and planning passes diverged: reported by build_plan
   return ex->ws + off;
 }
 static Tensor new_tensor(dsx_exec* ex, int C, int H, int W) {
@@ -600,6 +602,19 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   const bool is_wide = a.Cout > 64;
   const int kgroups = a.kchunks / conv_chunk_multiple(ks);
   ConvArgs c;
+  // Pass 0: the warp-specialised persistent kernel only needs ~one workgroup per CU: take the widest
+  // tile (least re-staging of the activations per output channel) that still gives >= ws_min work items.
+  static const int ws_on = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
+  static const int ws_min = getenv("DSX_WS_MIN_GRID") ? atoi(getenv("DSX_WS_MIN_GRID")) : 224;
+  static const std::vector<int> ws_wide = tile_order("DSX_TILES_WS_WIDE", {TILE_128x128, TILE_64x128});
+  static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_128x64, TILE_64x64});
+  if (ws_on && stride == 1 && a.stage_mode == 0) {
+    for (int tile : (is_wide ? ws_wide : ws_narrow)) {
+      if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
+      if (conv_ws_lds_bytes(dtype, tile, ks, c) == 0) continue;
+      if ((long long)c.m_tiles * c.n_tiles >= ws_min) { a = c; tile_out = tile; return true; }
+    }
+  }
   for (int tile : (is_wide ? wide : narrow)) {
     if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
     if ((long long)c.m_tiles * c.n_tiles >= min_grid) { a = c; tile_out = tile; return true; }
@@ -637,6 +652,8 @@ struct ConvSpec {
   bool up = false;
   int stride = 1;
   const float* gn_scale = nullptr; const float* gn_shift = nullptr;
+  bool has_gn = false;       // set by the planner, not derived from pointers (null during the sizing pass)
+  bool has_resid = false;
   bool swish = false;
   const float* film = nullptr; int film_bs = 0;
   const float* resid = nullptr; int resid_ld = 0;
@@ -651,6 +668,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   a.B = ex->B; a.Hs = s.x0.H; a.Ws = s.x0.W; a.up = s.up ? 1 : 0;
   a.Ho = s.out.H; a.Wo = s.out.W;
   a.gn_scale = s.gn_scale; a.gn_shift = s.gn_shift; a.swish = s.swish ? 1 : 0;
+  a.has_gn = s.has_gn ? 1 : 0;
   {
     const int gw = conv_chunk_multiple(s.w->ks) * (ex->m->dtype == 1 ? 32 : 16);  // channels per staged group
     a.stage_mode = ((a.C0 & 3) || (a.C1 & 3)) ? 2 : ((a.C1 == 0 || a.C0 % gw == 0) ? 0 : 1);
@@ -668,7 +686,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
   if (fuse_stats && s.want_stats && mfma_ok && conv_tile_fuses_stats(tile) && a.ksplit == 1 && a.tb_log2 == 0 &&
       (a.Cout & 3) == 0 &&
-      a.out_ld == a.Cout && (!a.resid || (a.resid_ld & 3) == 0)) {
+      a.out_ld == a.Cout && (a.resid_ld & 3) == 0) {
     StatInfo& si = ex->stats[s.out.id];
     si.nchunk = a.tiles_x * a.tiles_y * conv_tile_wm(tile);
     si.part = ws_alloc(ex, (size_t)a.B * si.nchunk * a.Cout * 2 * sizeof(float));
@@ -718,8 +736,21 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
              4.0 * (a.ksplit + 1) * (double)ra.M * ra.N,
              [=](hipStream_t st) { return launch_splitk_reduce(ra, st); });
     } else {
-      add_op(ex, DSX_OP_CONV_MFMA, d, flops, bytes,
-             [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
+      static const int ws_on = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
+      ConvArgs w = a;
+      w.ws_wg_per_n = std::min(a.m_tiles, std::max(1, 256 / std::max(1, a.n_tiles)));
+      if (a.n_tiles <= 8 && 8 % a.n_tiles == 0) {   // whole XCD groups per N tile (see k_conv_ws)
+        const int unit = 8 / a.n_tiles;
+        w.ws_wg_per_n = std::max(unit, w.ws_wg_per_n / unit * unit);
+        if (w.ws_wg_per_n > a.m_tiles) w.ws_wg_per_n = (a.m_tiles + unit - 1) / unit * unit;
+      }
+      if (ws_on && stride == 1 && a.stage_mode == 0 && (a.Cout & 3) == 0 && conv_ws_lds_bytes(dtype, tile, ks, w) != 0) {
+        add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
+               [=](hipStream_t st) { return launch_conv_ws(dtype, tile, ks, w, st); });
+      } else {
+        add_op(ex, DSX_OP_CONV_MFMA, d, flops, bytes,
+               [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
+      }
     }
   } else {
     if (!s.w->naive)
@@ -783,7 +814,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   Tensor h = new_tensor(ex, md.cout, H, W);
   ConvSpec c1{};
   c1.w = &md.conv1; c1.x0 = x0; if (x1) c1.x1 = *x1;
-  c1.gn_scale = s1; c1.gn_shift = h1; c1.swish = true;
+  c1.gn_scale = s1; c1.gn_shift = h1; c1.has_gn = true; c1.swish = true;
   if (md.film_off >= 0 && !ex->sizing) { c1.film = ex->film + md.film_off; c1.film_bs = ex->m->F; }
   c1.out = h; c1.want_stats = true;
   if ((rc = plan_conv(ex, c1))) return rc;
@@ -799,7 +830,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   }
   Tensor o = new_tensor(ex, md.cout, H, W);
   ConvSpec c2{};
-  c2.w = &md.conv2; c2.x0 = h; c2.gn_scale = s2; c2.gn_shift = h2; c2.swish = true;
+  c2.w = &md.conv2; c2.x0 = h; c2.gn_scale = s2; c2.gn_shift = h2; c2.has_gn = true; c2.swish = true;
   c2.resid = r.p; c2.resid_ld = md.cout; c2.out = o; c2.want_stats = true;
   if ((rc = plan_conv(ex, c2))) return rc;
   if (!md.attn) { y = o; return DSX_OK; }
@@ -809,7 +840,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   const int C = md.cout, L = H * W, B = ex->B;
   Tensor qkv = new_tensor(ex, 3 * C, H, W);
   ConvSpec cq{};
-  cq.w = &md.qkv; cq.x0 = o; cq.gn_scale = sa; cq.gn_shift = ha; cq.out = qkv;
+  cq.w = &md.qkv; cq.x0 = o; cq.gn_scale = sa; cq.gn_shift = ha; cq.has_gn = true; cq.out = qkv;
   if ((rc = plan_conv(ex, cq))) return rc;
   float* S = (float*)ws_alloc(ex, (size_t)B * L * L * sizeof(float));
   Tensor av = new_tensor(ex, C, H, W);
@@ -897,12 +928,14 @@ static int build_plan(dsx_exec* ex) {
       plan_gn(ex, md.gn1, x, nullptr, &s, &h);
       Tensor o = new_tensor(ex, md.cout, x.H, x.W);
       ConvSpec c{};
-      c.w = &md.conv; c.x0 = x; c.gn_scale = s; c.gn_shift = h; c.swish = true; c.out = o;
+      c.w = &md.conv; c.x0 = x; c.gn_scale = s; c.gn_shift = h; c.has_gn = true; c.swish = true; c.out = o;
       if ((rc = plan_conv(ex, c))) return rc;
       x = o;
     }
   }
   ex->out = x;
+  if (ex->overflow)
+    return fail(DSX_ERR_STATE, "internal error: the planning pass needs more workspace than the sizing pass reserved");
   return DSX_OK;
 }
 
@@ -976,10 +1009,13 @@ extern "C" int dsx_exec_profile(dsx_exec* ex, int iters, float* ms_per_op, void*
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   std::vector<double> acc(n, 0.0);
   for (int it = 0; it < iters; ++it) {
+    static const bool trace = getenv("DSX_TRACE") != nullptr;   // debugging: name each launch, sync after it
     for (size_t i = 0; i < n; ++i) {
+      if (trace) { fprintf(stderr, "[dsx] op %zu: %s\n", i, ex->op_info[i].desc.c_str()); fflush(stderr); }
       HIP_TRY(hipEventRecord(ev[2 * i], st));
       HIP_TRY(ex->ops[i](st));
       HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
+      if (trace) HIP_TRY(hipStreamSynchronize(st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     for (size_t i = 0; i < n; ++i) {
