@@ -112,7 +112,7 @@ def roofline(eng, ex, dtype, iters=3):
     total_ms = sum(r[4] for r in rows)
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    traffic = None
+    traffic = None   # HBM bytes per conv launch from rocprofv3 PMC passes (profiles/traffic.json), not measurable live
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -135,7 +135,7 @@ def roofline(eng, ex, dtype, iters=3):
     for r in top:
         tf = r[2] / (r[4] * 1e-3) / 1e12 if r[4] > 0 else 0.0
         print(f"[bench]   {r[4]:8.4f} ms  {tf:8.1f} TF/s  {r[1]}", file=sys.stderr)
-    return {"bound": "mfma", "kernel": "k_conv_mfma (all launches of one UNet forward)",
+    return {"bound": "mfma", "kernel": "k_conv_ws / k_conv_mfma (fused GN+Swish+conv implicit GEMM; all conv launches of one UNet forward)",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "launches": len(conv), "avg_launch_ms": conv_ms / max(1, len(conv)),
             "conv_ms_per_step": conv_ms, "all_kernels_ms_per_step": total_ms}
