@@ -90,23 +90,31 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
   const int cpg = C / a.groups;
   const int c_lo = g * cpg;
   double s = 0, q = 0;
-  // channels of this group that live in source 0 / source 1
+  // channels of this group that live in source 0 / source 1; the loads of a lane are independent, so
+  // they are issued 8 at a time (the kernel is pure load latency otherwise)
   const int n0 = max(0, min(a.C0, c_lo + cpg) - c_lo);      // first n0 channels from source 0
-  const int items0 = n0 * a.nchunk0;
-  for (int i = lane; i < items0; i += 64) {
-    const int ch = i / n0, c = c_lo + (i - ch * n0);
-    const size_t idx = (((size_t)b * a.nchunk0 + ch) * a.C0 + c) * 2;
-    if (a.f32_0) { const float* p = (const float*)a.part0 + idx; s += p[0]; q += p[1]; }
-    else { const double* p = (const double*)a.part0 + idx; s += p[0]; q += p[1]; }
-  }
   const int n1 = cpg - n0;
-  const int items1 = n1 * a.nchunk1;
-  for (int i = lane; i < items1; i += 64) {
-    const int ch = i / n1, c = c_lo + n0 + (i - ch * n1) - a.C0;
-    const size_t idx = (((size_t)b * a.nchunk1 + ch) * a.C1 + c) * 2;
-    if (a.f32_1) { const float* p = (const float*)a.part1 + idx; s += p[0]; q += p[1]; }
-    else { const double* p = (const double*)a.part1 + idx; s += p[0]; q += p[1]; }
-  }
+  auto accumulate = [&](const void* part, int is_f32, int nsrc, int nchunk, int Csrc, int cbase) {
+    const int items = nsrc * nchunk;
+    for (int i0 = lane; i0 < items; i0 += 64 * 8) {
+      double ps[8], pq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 64;
+        ps[u] = 0; pq[u] = 0;
+        if (i < items) {
+          const int ch = i / nsrc, c = cbase + (i - ch * nsrc);
+          const size_t idx = (((size_t)b * nchunk + ch) * Csrc + c) * 2;
+          if (is_f32) { const float2 v = *(const float2*)((const float*)part + idx); ps[u] = v.x; pq[u] = v.y; }
+          else { const double2 v = *(const double2*)((const double*)part + idx); ps[u] = v.x; pq[u] = v.y; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += ps[u]; q += pq[u]; }
+    }
+  };
+  if (n0 > 0) accumulate(a.part0, a.f32_0, n0, a.nchunk0, a.C0, c_lo);
+  if (n1 > 0) accumulate(a.part1, a.f32_1, n1, a.nchunk1, a.C1, c_lo + n0 - a.C0);
   s = wave_sum(s); q = wave_sum(q);
   const double n = a.count * cpg;
   const double mean = s / n;
@@ -198,8 +206,12 @@ hipError_t launch_temb(const TembArgs& a, hipStream_t st) {
 // one-float-per-lane operand reads).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bgemm(const BgemmArgs a) {
-  __shared__ float As[64 * 17];
-  __shared__ float Bs[64 * 17];
+  // K chunks of 32 through LDS ([row][33] floats: conflict-free for the fill and for the
+  // one-float-per-lane operand reads); the next chunk's global loads are issued before the
+  // current chunk's MFMAs (register double buffering), since the kernel is load-latency-bound.
+  constexpr int KC = 32, LD = KC + 1;
+  __shared__ float As[64 * LD];
+  __shared__ float Bs[64 * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -212,60 +224,75 @@ __global__ __launch_bounds__(256) void k_bgemm(const BgemmArgs a) {
   const float* Bm = a.Bm + (size_t)bt * a.sB;
   float* Cm = a.Cm + (size_t)bt * a.sC;
 
+  // row-major [row][k] operand (A, or B when !b_kmajor): thread -> (row = tid/4, 8 consecutive k)
+  auto load_rk = [&](const float* base, int ld, int row0, int rows, int k0, float4 out[2]) {
+    const int r = tid >> 2, kk = (tid & 3) * 8;
+    out[0] = out[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < rows) {
+      const float* p = base + (size_t)(row0 + r) * ld + k0 + kk;
+      if (k0 + kk + 7 < a.K && (ld & 3) == 0) {
+        out[0] = *(const float4*)p;
+        out[1] = *(const float4*)(p + 4);
+      } else {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (k0 + kk + j < a.K) ? p[j] : 0.f;
+        out[0] = make_float4(e[0], e[1], e[2], e[3]);
+        out[1] = make_float4(e[4], e[5], e[6], e[7]);
+      }
+    }
+  };
+  auto store_rk = [&](float* S, const float4 v[2]) {
+    const int r = tid >> 2, kk = (tid & 3) * 8;
+    float* d = S + r * LD + kk;
+    d[0] = v[0].x; d[1] = v[0].y; d[2] = v[0].z; d[3] = v[0].w;
+    d[4] = v[1].x; d[5] = v[1].y; d[6] = v[1].z; d[7] = v[1].w;
+  };
+  // k-major B[k][n]: thread -> (k = tid/8, 8 consecutive n), stored transposed as Bs[n][k]
+  auto load_kn = [&](int k0, float4 out[2]) {
+    const int kk = tid >> 3, nn = (tid & 7) * 8;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    if (k0 + kk < a.K) {
+      const float* p = Bm + (size_t)(k0 + kk) * a.ldb + n0 + nn;
+      if (n0 + nn + 7 < a.N && (a.ldb & 3) == 0) {
+        const float4 u = *(const float4*)p, w = *(const float4*)(p + 4);
+        e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w; e[4] = w.x; e[5] = w.y; e[6] = w.z; e[7] = w.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (n0 + nn + j < a.N) e[j] = p[j];
+      }
+    }
+    out[0] = make_float4(e[0], e[1], e[2], e[3]);
+    out[1] = make_float4(e[4], e[5], e[6], e[7]);
+  };
+  auto store_kn = [&](const float4 v[2]) {
+    const int kk = tid >> 3, nn = (tid & 7) * 8;
+    const float e[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Bs[(nn + j) * LD + kk] = e[j];
+  };
+
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int k0 = 0; k0 < a.K; k0 += 16) {
-    // A tile: 64 rows x 16 k; thread -> (row = tid/4, 4 consecutive k)
-    {
-      const int r = tid >> 2, kk = (tid & 3) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + r < a.M) {
-        const float* p = A + (size_t)(m0 + r) * a.lda + k0 + kk;
-        if (k0 + kk + 3 < a.K && (a.lda & 3) == 0) v = *(const float4*)p;
-        else {
-          if (k0 + kk < a.K) v.x = p[0];
-          if (k0 + kk + 1 < a.K) v.y = p[1];
-          if (k0 + kk + 2 < a.K) v.z = p[2];
-          if (k0 + kk + 3 < a.K) v.w = p[3];
-        }
-      }
-      float* d = As + r * 17 + kk;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    if (!a.b_kmajor) {
-      const int r = tid >> 2, kk = (tid & 3) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + r < a.N) {
-        const float* p = Bm + (size_t)(n0 + r) * a.ldb + k0 + kk;
-        if (k0 + kk + 3 < a.K && (a.ldb & 3) == 0) v = *(const float4*)p;
-        else {
-          if (k0 + kk < a.K) v.x = p[0];
-          if (k0 + kk + 1 < a.K) v.y = p[1];
-          if (k0 + kk + 2 < a.K) v.z = p[2];
-          if (k0 + kk + 3 < a.K) v.w = p[3];
-        }
-      }
-      float* d = Bs + r * 17 + kk;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    } else {
-      // B[k][n]: thread -> (k = tid/16, 4 consecutive n), stored transposed as Bs[n][k]
-      const int kk = tid >> 4, nn = (tid & 15) * 4;
-      float e[4] = {0.f, 0.f, 0.f, 0.f};
-      if (k0 + kk < a.K) {
-        const float* p = Bm + (size_t)(k0 + kk) * a.ldb + n0 + nn;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (n0 + nn + j < a.N) e[j] = p[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Bs[(nn + j) * 17 + kk] = e[j];
-    }
+  float4 ra[2], rb[2];
+  load_rk(A, a.lda, m0, a.M, 0, ra);
+  if (!a.b_kmajor) load_rk(Bm, a.ldb, n0, a.N, 0, rb); else load_kn(0, rb);
+  for (int k0 = 0; k0 < a.K; k0 += KC) {
+    store_rk(As, ra);
+    if (!a.b_kmajor) store_rk(Bs, rb); else store_kn(rb);
     __syncthreads();
+    if (k0 + KC < a.K) {   // prefetch the next chunk while this one is multiplied
+      load_rk(A, a.lda, m0, a.M, k0 + KC, ra);
+      if (!a.b_kmajor) load_rk(Bm, a.ldb, n0, a.N, k0 + KC, rb); else load_kn(k0 + KC, rb);
+    }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const float av = As[(wm * 32 + li) * 17 + 2 * s + lh];
-      const float bv = Bs[(wn * 32 + li) * 17 + 2 * s + lh];
+    for (int s = 0; s < KC / 2; ++s) {
+      const float av = As[(wm * 32 + li) * LD + 2 * s + lh];
+      const float bv = Bs[(wn * 32 + li) * LD + 2 * s + lh];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
     __syncthreads();

@@ -606,7 +606,7 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   // tile (least re-staging of the activations per output channel) that still gives >= ws_min work items.
   static const int ws_on = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
   static const int ws_min = getenv("DSX_WS_MIN_GRID") ? atoi(getenv("DSX_WS_MIN_GRID")) : 224;
-  static const std::vector<int> ws_wide = tile_order("DSX_TILES_WS_WIDE", {TILE_128x128, TILE_64x128});
+  static const std::vector<int> ws_wide = tile_order("DSX_TILES_WS_WIDE", {TILE_64x128, TILE_128x128});
   static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_128x64, TILE_64x64});
   if (ws_on && stride == 1 && a.stage_mode == 0) {
     for (int tile : (is_wide ? ws_wide : ws_narrow)) {
