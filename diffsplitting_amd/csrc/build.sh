@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libdsx.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $DSX_EXTRA_FLAGS"
 mkdir -p _obj
 for f in dsx_conv.hip dsx_ops.hip; do
   if [ ! -f _obj/$f.o ] || [ $f -nt _obj/$f.o ] || [ dsx_kernels.h -nt _obj/$f.o ]; then

@@ -53,6 +53,42 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// 16 per-lane registers -> one total per lane: lane i of a DPP row ends up with the row's sum of register
+// r = 8*bit0(i) + 4*bit1(i) + 2*bit2(i) + bit3(i).  Each butterfly stage halves the register count (the
+// lane keeps the half its bit selects and receives the partner's copy of that half): 15 adds instead of
+// the 64 of sixteen row16_sum calls.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                               CTRL, 0xF, BANKS, false));
+}
+__device__ __forceinline__ float row16_fold(const float (&s)[16], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  float a8[8], a4[4], a2[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float keep = b0 ? s[k + 8] : s[k], send = b0 ? s[k] : s[k + 8];
+    a8[k] = keep + dpp_take<0xB1, 0xF>(0.f, send);                       // lane ^ 1
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float keep = b1 ? a8[k + 4] : a8[k], send = b1 ? a8[k] : a8[k + 4];
+    a4[k] = keep + dpp_take<0x4E, 0xF>(0.f, send);                       // lane ^ 2
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float keep = b2 ? a4[k + 2] : a4[k], send = b2 ? a4[k] : a4[k + 2];
+    float t = dpp_take<0x104, 0x5>(0.f, send);                           // banks 0,2 <- lane + 4
+    t = dpp_take<0x114, 0xA>(t, send);                                   // banks 1,3 <- lane - 4
+    a2[k] = keep + t;
+  }
+  const float keep = b3 ? a2[1] : a2[0], send = b3 ? a2[0] : a2[1];
+  return keep + dpp_take<0x128, 0xF>(0.f, send);                         // lane ^ 8 (row_ror:8)
+}
+__device__ __forceinline__ int row16_fold_reg(int lane) {
+  return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+}
+
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   __bf16 l = (__bf16)lo, h = (__bf16)hi;  // RNE (v_cvt_pk_bf16_f32)
   unsigned short ls = __builtin_bit_cast(unsigned short, l);
@@ -780,8 +816,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     for (int dy = 0; dy < KS; ++dy)
       abase[mb][dy] = (tb * PH + ty * S + dy) * RB + tx * S * PIXB + lh * 16;
   }
-  int blk = nt * WN + wn;
-  if (blk >= a.nblocks) blk = a.nblocks - 1;
+  const int blk = nt * WN + wn;                 // host: Cout % (32 * WN) == 0, so every block exists
   const long long wblock = (long long)G * (NSTEP * 1024);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const unsigned char*)a.wpack + (size_t)blk * wblock), 0, (int)wblock, 0x00020000);
@@ -805,21 +840,76 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 
   constexpr bool STATS = MB <= 2;
   const bool do_stats = STATS && a.stat_part != nullptr;
-  const int nbase = (nt * WN + wn) * 32 + 4 * lh;
+  const int nbase = blk * 32 + 4 * lh;
 
-  // GroupNorm scale/shift of tile `t`'s image -> LDS (parity slot), for the loader waves
-  auto load_aff = [&](int t) {
-    if (a.gn_scale == nullptr || t >= ntile) return;
-    int oy0, ox0, b0;
-    tile_coords(t, oy0, ox0, b0);
-    float* dst = aff_base + (size_t)(t & 1) * (AFFB / 4);
-    for (int i = tid * 4; i < C; i += 1024) {
-      *(float4*)(dst + i) = *(const float4*)(a.gn_scale + (size_t)b0 * C + i);
-      *(float4*)(dst + C + i) = *(const float4*)(a.gn_shift + (size_t)b0 * C + i);
+  // Tile walk without divisions: (tx, ty, image) of tile p0 + k*wpn, advanced by the decomposed stride.
+  struct TilePos { int tx, ty, b; };
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int adv_x = wpn % a.tiles_x, adv_y = (wpn / a.tiles_x) % a.tiles_y, adv_b = wpn / per_img;
+  auto tile_advance = [&](TilePos& t) {
+    t.tx += adv_x;
+    if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; t.ty += 1; }
+    t.ty += adv_y;
+    if (t.ty >= a.tiles_y) { t.ty -= a.tiles_y; t.b += 1; }
+    t.b += adv_b;
+  };
+  // output pixel of this lane's row in M block mb of tile t
+  auto out_pixel = [&](const TilePos& t, int mb) -> size_t {
+    const int m = (wm * MB + mb) * 32 + li;
+    const int tx = m & (TW - 1), ty = m >> a.tw_log2;
+    return ((size_t)t.b * a.Ho + ((t.ty << a.th_log2) + ty)) * a.Wo + ((t.tx << a.tw_log2) + tx);
+  };
+  TilePos cur{p0 % a.tiles_x, (p0 / a.tiles_x) % a.tiles_y, p0 / per_img};   // tile ti (being multiplied)
+  TilePos nxt = cur;       // tile ti + 1
+  tile_advance(nxt);
+  TilePos nn = nxt;        // tile ti + 2
+  tile_advance(nn);
+
+  // GroupNorm scale/shift of image b -> LDS parity slot, for the loader waves (host: C <= 1024)
+  auto load_aff = [&](int b, int slot) {
+    if (a.gn_scale == nullptr || tid * 4 >= C) return;
+    float* dst = aff_base + (size_t)slot * (AFFB / 4);
+    *(float4*)(dst + tid * 4) = *(const float4*)(a.gn_scale + (size_t)b * C + tid * 4);
+    *(float4*)(dst + C + tid * 4) = *(const float4*)(a.gn_shift + (size_t)b * C + tid * 4);
+  };
+  load_aff(cur.b, 0);
+  if (ntile > 1) load_aff(nxt.b, 1);
+
+  // Epilogue operands live in registers and are fetched one tile ahead, at the start of the previous tile's
+  // epilogue (right after its own operands were consumed): the loads then have the rest of that epilogue
+  // plus the 18 ring steps to land before an in-order vmcnt wait of the weight ring can trip over them.
+  // Bias is fetched once (the workgroup never changes its N tile).  Missing operands stay 0.0f: exact.
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 biasv[4], filmv[4], residv[MB][4], affv[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    biasv[j] = a.bias ? *(const float4*)(a.bias + nbase + 8 * j) : zero4;
+    filmv[j] = zero4;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) residv[mb][j] = zero4;
+  }
+  affv[0] = affv[1] = zero4;
+  // t: the tile whose epilogue will use the operands; b_aff: image of the tile two after it
+  auto prefetch_epilogue = [&](const TilePos& t, bool want_aff, int b_aff) {
+    if (a.film) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) filmv[j] = *(const float4*)(a.film + (size_t)t.b * a.film_bs + nbase + 8 * j);
+    }
+    if (a.resid) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float* rp = a.resid + out_pixel(t, mb) * a.resid_ld + nbase;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) residv[mb][j] = *(const float4*)(rp + 8 * j);
+      }
+    }
+    if (want_aff && a.gn_scale != nullptr && tid * 4 < C) {
+      affv[0] = *(const float4*)(a.gn_scale + (size_t)b_aff * C + tid * 4);
+      affv[1] = *(const float4*)(a.gn_shift + (size_t)b_aff * C + tid * 4);
     }
   };
-  load_aff(0);
-  load_aff(1);
+  prefetch_epilogue(cur, ntile > 2, nn.b);
+
   ws_barrier();   // scale/shift visible to the loaders
   ws_barrier();   // image of item 0 is ready
   DSX_STAMP_T(0, tid == 0);
@@ -855,69 +945,61 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     DSX_STAMP_T(2 + 3 * v, tid == 0 && v < 20);
     if (++g < G) continue;
     g = 0;
-    load_aff(ti + 2);   // tile ti+1's is already there; slot parity of ti+2 == ti, whose use has ended
 
-    // ---- tile finished: epilogue (+ fused statistics), same layout as k_conv_mfma
-    int oy0, ox0, b0;
-    tile_coords(ti, oy0, ox0, b0);
-    const int mt = p0 + ti * wpn;
+    // ---- tile finished: epilogue (+ fused statistics).  Accumulator register r of a lane is channel
+    //      (r & 3) + 8 * (r >> 2) + 4 * lh of the wave's 32-channel block, for the lane's pixel.
+    // scale/shift of tile ti+2 -> LDS (tile ti+1's is already there; slot parity of ti+2 == ti, whose use has ended)
+    if (a.gn_scale != nullptr && ti + 2 < ntile && tid * 4 < C) {
+      float* dst = aff_base + (size_t)(ti & 1) * (AFFB / 4);
+      *(float4*)(dst + tid * 4) = affv[0];
+      *(float4*)(dst + C + tid * 4) = affv[1];
+    }
+    // reference order: conv -> + bias -> + FiLM -> + residual
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 tb = biasv[j], tf = filmv[j], tr = residv[mb][j];
+        acc[mb][4 * j + 0] = ((acc[mb][4 * j + 0] + tb.x) + tf.x) + tr.x;
+        acc[mb][4 * j + 1] = ((acc[mb][4 * j + 1] + tb.y) + tf.y) + tr.y;
+        acc[mb][4 * j + 2] = ((acc[mb][4 * j + 2] + tb.z) + tf.z) + tr.z;
+        acc[mb][4 * j + 3] = ((acc[mb][4 * j + 3] + tb.w) + tf.w) + tr.w;
+      }
+    DSX_STAMP_T(61, tid == 0 && ti == 1);
+    // the operand registers are free again: fetch the next tile's (and the scale/shift of tile ti+3)
+    const TilePos done = cur;
     ++ti;
-    const bool vec = (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (!a.resid || (a.resid_ld & 3) == 0);
+    cur = nxt; nxt = nn; tile_advance(nn);
+    if (ti < ntile) prefetch_epilogue(cur, ti + 2 < ntile, nn.b);
+
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      const int m = (wm * MB + mb) * 32 + li;
-      const int tx = m & (TW - 1);
-      const int ty = (m >> a.tw_log2) & (TH - 1);
-      const int b = b0 + (m >> (a.tw_log2 + a.th_log2));
-      if (b < a.B) {
-        const size_t opix = ((size_t)b * a.Ho + (oy0 + ty)) * a.Wo + (ox0 + tx);
+      float* op = a.out + out_pixel(done, mb) * a.out_ld + nbase;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = nbase + 8 * j;
-          if (n >= a.Cout) continue;
-          float x[4] = {acc[mb][4 * j], acc[mb][4 * j + 1], acc[mb][4 * j + 2], acc[mb][4 * j + 3]};
-          if (vec) {
-            if (a.bias) { const float4 t = *(const float4*)(a.bias + n); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
-            if (a.film) { const float4 t = *(const float4*)(a.film + (size_t)b * a.film_bs + n); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
-            if (a.resid) { const float4 t = *(const float4*)(a.resid + opix * a.resid_ld + n); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
-            *(float4*)(a.out + opix * a.out_ld + n) = make_float4(x[0], x[1], x[2], x[3]);
-            if (do_stats) {
+      for (int j = 0; j < 4; ++j)
+        *(float4*)(op + 8 * j) = make_float4(acc[mb][4 * j], acc[mb][4 * j + 1], acc[mb][4 * j + 2], acc[mb][4 * j + 3]);
+      if constexpr (STATS) {
 #pragma unroll
-              for (int k = 0; k < 4; ++k) { s1[4 * j + k] += x[k]; s2[4 * j + k] += x[k] * x[k]; }
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (n + k >= a.Cout) break;
-              float y = x[k];
-              if (a.bias) y += a.bias[n + k];
-              if (a.film) y += a.film[(size_t)b * a.film_bs + n + k];
-              if (a.resid) y += a.resid[opix * a.resid_ld + n + k];
-              a.out[opix * a.out_ld + n + k] = y;
-            }
-          }
-        }
+        for (int r = 0; r < 16; ++r) { s1[r] += acc[mb][r]; s2[r] += acc[mb][r] * acc[mb][r]; }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
     }
+    DSX_STAMP_T(62, tid == 0 && ti == 2);
     if (do_stats) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
-      float w1 = s1[0], w2 = s2[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) { if ((li & 15) == r) { w1 = s1[r]; w2 = s2[r]; } }
+      // lane (li & 15) holds register row16_fold_reg(li), summed over its 16 pixels; add the other row's copy
+      float w1 = row16_fold(s1, lane), w2 = row16_fold(s2, lane);
       w1 += __shfl_xor(w1, 16, 64);
       w2 += __shfl_xor(w2, 16, 64);
-      const int per_img = a.tiles_x * a.tiles_y;
-      const int chunk = (mt % per_img) * WM + wm;
+      const int chunk = (done.ty * a.tiles_x + done.tx) * WM + wm;
       const int nch = per_img * WM;
-      const int n = (nt * WN + wn) * 32 + (li & 3) + 8 * (li >> 2) + 4 * lh;
-      if (li < 16 && n < a.Cout) {
-        float* pp = a.stat_part + (((size_t)b0 * nch + chunk) * a.Cout + n) * 2;
+      const int r = row16_fold_reg(li);
+      const int n = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (li < 16) {
+        float* pp = a.stat_part + (((size_t)done.b * nch + chunk) * a.Cout + n) * 2;
         pp[0] = w1; pp[1] = w2;
       }
     }
@@ -1032,13 +1114,13 @@ hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& 
 
 // ---- warp-specialised variant: per (dtype, tile, ks) constants
 static constexpr bool ws_tile_ok(int tile) {
-  return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;
+  return tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;   // MB <= 2: epilogue operands fit in registers
 }
 static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activations in flight beyond the current one
   const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
   return bm == 64 ? 4 : (ks == 1 ? 2 : 3);
 }
-static constexpr int kWsLoaderWaves = 8;
+static constexpr int kWsLoaderWaves = 4;
 static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units per loader thread per group
   const int upg = (dtype == 1 ? 8 : 4) * conv_cpg(ks);
   return (max_px(tile, ks, 1) * upg + kWsLoaderWaves * 64 - 1) / (kWsLoaderWaves * 64);
@@ -1052,6 +1134,8 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   const size_t affb = a.has_gn ? (((size_t)2 * (a.C0 + a.C1) * 4 + 15) & ~(size_t)15) : 0;  // never keyed on a pointer
   const size_t total = 2 * bufb + 2 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb;
   if (a.tb_log2 != 0 || a.kchunks / conv_cpg(ks) < 2) return 0;   // one image per tile, >= 2 channel groups
+  // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
+  if (a.Cout % (32 * kTiles[tile].WN) != 0 || (a.out_ld & 3) != 0 || (a.resid_ld & 3) != 0 || a.C0 + a.C1 > 1024) return 0;
   return total <= 160 * 1024 ? total : 0;
 }
 

@@ -41,3 +41,8 @@ for v in range(15):
     if a == 0: break
     print("  item %2d: issue %5d  wait %6d  consume %6d  barrier %6d" % (v, a - prev, (b - a) if b else 0, (c - b) if b else (c - a), d - c))
     prev = d
+# second tile's epilogue breakdown (stamps 61: after load_aff, 62: after the store loop)
+eps = [v for v in range(20) if st[3 + 3*v] > 0 and st[1 + 3*v] > 0]
+if len(eps) >= 2 and st[61] > 0:
+    v = eps[1]; b, e = st[2 + 3*v], st[3 + 3*v]
+    print("epilogue of tile 1: load_aff %d | loads+adds+stores %d | stats %d" % (st[61] - b, st[62] - st[61], e - st[62]))
