@@ -114,6 +114,69 @@ template <typename DT> struct Chunk;
 template <> struct Chunk<float> { static constexpr int KC = 16; };
 template <> struct Chunk<__bf16> { static constexpr int KC = 32; };
 
+// Activations live in HBM in the MFMA operand type (fp32 or bf16); everything is staged in 16-byte units:
+// Unit<DT>::N consecutive channels of one pixel (4 fp32 / 8 bf16), which is also 16 bytes of the LDS image.
+template <typename DT> struct Unit;
+template <> struct Unit<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(const uint4 r, float (&v)[4]) {
+    v[0] = __builtin_bit_cast(float, r.x); v[1] = __builtin_bit_cast(float, r.y);
+    v[2] = __builtin_bit_cast(float, r.z); v[3] = __builtin_bit_cast(float, r.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float (&v)[4]) {
+    return make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                      __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+  }
+};
+template <> struct Unit<__bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void unpack(const uint4 r, float (&v)[8]) {
+    v[0] = __builtin_bit_cast(float, r.x << 16); v[1] = __builtin_bit_cast(float, r.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, r.y << 16); v[3] = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    v[4] = __builtin_bit_cast(float, r.z << 16); v[5] = __builtin_bit_cast(float, r.z & 0xffff0000u);
+    v[6] = __builtin_bit_cast(float, r.w << 16); v[7] = __builtin_bit_cast(float, r.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint4 pack(const float (&v)[8]) {
+    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                      pack_bf16x2(v[6], v[7]));
+  }
+};
+// one activation element -> float (scalar fallback paths)
+template <typename DT> __device__ __forceinline__ float act_load(const void* p, size_t i) {
+  if constexpr (sizeof(DT) == 2) return __builtin_bit_cast(float, (unsigned)((const unsigned short*)p)[i] << 16);
+  else return ((const float*)p)[i];
+}
+__device__ __forceinline__ void act_store(void* p, size_t i, float v, bool bf16) {
+  if (bf16) {
+    const __bf16 h = (__bf16)v;
+    ((unsigned short*)p)[i] = __builtin_bit_cast(unsigned short, h);
+  } else {
+    ((float*)p)[i] = v;
+  }
+}
+// Accumulator layout of every conv kernel here (weights are the MFMA A operand, packed with permuted
+// rows, see pack_conv): lane (li = lane & 31, lh = lane >> 5) holds pixel li of its row block, register r
+// holds channel 16*lh + r of the wave's 32-channel block -> 16 consecutive channels per lane.
+// x[16] -> out (+ optional 16-B vector stores); `n0` = first channel, `valid` = channels that exist
+template <bool VEC>
+__device__ __forceinline__ void store16(void* out, size_t elem, const float (&x)[16], bool bf16, int valid) {
+  if (VEC) {
+    if (bf16) {
+      uint4* q = (uint4*)((unsigned short*)out + elem);
+      q[0] = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+      q[1] = make_uint4(pack_bf16x2(x[8], x[9]), pack_bf16x2(x[10], x[11]), pack_bf16x2(x[12], x[13]), pack_bf16x2(x[14], x[15]));
+    } else {
+      float4* q = (float4*)((float*)out + elem);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = make_float4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r < valid) act_store(out, elem + r, x[r], bf16);
+  }
+}
+
 // MB   : 32-row M blocks per wave;  WM x WN waves (WM*WN == 4); every wave owns ONE
 //        32-channel N block, so with WM == 1 no weight fragment is loaded twice.
 // CPG  : channel chunks staged per barrier ("group"); 1 for 3x3, 2 for 1x1 (few steps per chunk)
@@ -127,17 +190,19 @@ template <> struct Chunk<__bf16> { static constexpr int KC = 32; };
 template <typename DT, int MB, int WM, int WN, int KS, int S, int CPG, int D, int MAX_IT>
 __global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1)))) void k_conv_mfma(const ConvArgs a) {
   constexpr int KC = Chunk<DT>::KC;
-  constexpr int UPP = KC / 4;                 // 4-channel staging units per pixel per chunk
+  constexpr int CPU = Unit<DT>::N;            // channels per 16-byte staging unit
+  constexpr int ES = (int)sizeof(DT);         // bytes per activation element in HBM
+  constexpr int UPP = KC / CPU;               // staging units per pixel per chunk (4)
   constexpr int UPG = UPP * CPG;              // ... per group
   constexpr int UPG_LOG2 = UPG == 16 ? 4 : (UPG == 8 ? 3 : 2);
-  constexpr int UB = 4 * (int)sizeof(DT);     // LDS bytes per staging unit
+  constexpr int UB = 16;                      // LDS bytes per staging unit
   constexpr int PIXB = 64 * CPG + 16;         // LDS bytes per patch pixel
   constexpr int TAPS = KS * KS;
   constexpr int PAD = KS / 2;
   constexpr int NSTEP = CPG * TAPS * 2;       // MFMA steps per group: (chunk, tap, 32-B half)
   constexpr bool IS_BF16 = sizeof(DT) == 2;
   static_assert(NSTEP % D == 0, "ring depth must divide the steps per group");
-  static_assert(WM * WN == 4, "4 waves");
+  static_assert(WM * WN == 4 && UPP == 4, "4 waves; 64-byte chunks");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -177,7 +242,7 @@ __global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1
   // Unit u = tid + 256*it covers patch pixel u >> UPG_LOG2; (tb, py, px) advance by a fixed stride
   // per `it`, so only the first unit needs integer divisions.
   const int nunits = PP << UPG_LOG2;
-  const int cvg = tid & (UPG - 1);  // this thread's 4-channel unit inside a group (same for all its units)
+  const int cvg = tid & (UPG - 1);  // this thread's unit inside a group (same for all its units)
   int soff[MAX_IT];   // source pixel index, or -1 (zero padding / outside batch / no such unit)
   int loff[MAX_IT];   // LDS byte offset of the unit inside a buffer, or -1
   int simg[MAX_IT];   // image index (GroupNorm scale/shift lookup when a tile spans images)
@@ -226,10 +291,10 @@ __global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1
 
   // ---- buffer descriptors (wave-uniform): activations (two sources) and this wave's weight stream
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)a.src0, 0, (int)min((long long)a.B * a.Hs * a.Ws * a.C0 * 4, 0x7fffffffLL), 0x00020000);
+      (void*)a.src0, 0, (int)min((long long)a.B * a.Hs * a.Ws * a.C0 * ES, 0x7fffffffLL), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(a.src1 ? a.src1 : a.src0), 0,
-      a.src1 ? (int)min((long long)a.B * a.Hs * a.Ws * a.C1 * 4, 0x7fffffffLL) : 0, 0x00020000);
+      a.src1 ? (int)min((long long)a.B * a.Hs * a.Ws * a.C1 * ES, 0x7fffffffLL) : 0, 0x00020000);
   int blk = nt * WN + wn;
   if (blk >= a.nblocks) blk = a.nblocks - 1;  // results of a clamped block are never stored
   const long long wblock = (long long)kgroups * (NSTEP * 1024);  // bytes of one N block's fragment stream
@@ -249,79 +314,86 @@ __global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
 
-  float4 stg[MAX_IT];
+  uint4 stg[MAX_IT];   // raw 16-byte units (CPU channels in the storage type)
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int it = 0; it < MAX_IT; ++it) stg[it] = make_uint4(0u, 0u, 0u, 0u);
 
   // issue the global loads of group g into registers
   auto stage_load = [&](int g) {
-    const int c = g * (CPG * KC) + cvg * 4;
+    const int c = g * (CPG * KC) + cvg * CPU;
     if (a.ablate & 2) return;   // timing experiments only (DSX_ABLATE): skip activation loads
     if (a.stage_mode == 0) {
       // fast path (both channel counts multiples of the group width): the whole workgroup reads ONE
       // source in this group -> wave-uniform descriptor, offsets by the memory pipeline, OOB -> 0
       const bool first = g * (CPG * KC) < a.C0;            // uniform
       const int cs = first ? a.C0 : a.C1;
-      const unsigned coff = c < C ? (unsigned)((first ? c : c - a.C0) * 4) : 0x80000000u;
+      const unsigned coff = c < C ? (unsigned)((first ? c : c - a.C0) * ES) : 0x80000000u;
       if (first) {
 #pragma unroll
         for (int it = 0; it < MAX_IT; ++it) {
-          const unsigned vo = soff[it] >= 0 ? (unsigned)soff[it] * (unsigned)(cs * 4) + coff : 0x80000000u;
-          stg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
+          const unsigned vo = soff[it] >= 0 ? (unsigned)soff[it] * (unsigned)(cs * ES) + coff : 0x80000000u;
+          stg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
         }
       } else {
 #pragma unroll
         for (int it = 0; it < MAX_IT; ++it) {
-          const unsigned vo = soff[it] >= 0 ? (unsigned)soff[it] * (unsigned)(cs * 4) + coff : 0x80000000u;
-          stg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0));
+          const unsigned vo = soff[it] >= 0 ? (unsigned)soff[it] * (unsigned)(cs * ES) + coff : 0x80000000u;
+          stg[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0));
         }
       }
     } else if (a.stage_mode == 1) {
-      // channel counts multiples of 4 but a group may straddle the two sources: per-lane source select
+      // channel counts multiples of the unit but a group may straddle the two sources: per-lane source select
 #pragma unroll
       for (int it = 0; it < MAX_IT; ++it) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
         const int so = soff[it];
         if (so >= 0) {
-          if (c < a.C0) v = *(const float4*)(a.src0 + (size_t)so * a.C0 + c);
-          else if (c < C) v = *(const float4*)(a.src1 + (size_t)so * a.C1 + (c - a.C0));
+          if (c < a.C0) v = *(const uint4*)((const DT*)a.src0 + (size_t)so * a.C0 + c);
+          else if (c < C) v = *(const uint4*)((const DT*)a.src1 + (size_t)so * a.C1 + (c - a.C0));
         }
         stg[it] = v;
       }
     } else {
 #pragma unroll
       for (int it = 0; it < MAX_IT; ++it) {
-        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        float e[CPU];
+#pragma unroll
+        for (int j = 0; j < CPU; ++j) e[j] = 0.f;
         const int so = soff[it];
         if (so >= 0) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < CPU; ++j) {
             const int cc = c + j;
-            if (cc < a.C0) e[j] = a.src0[(size_t)so * a.C0 + cc];
-            else if (cc < C) e[j] = a.src1[(size_t)so * a.C1 + (cc - a.C0)];
+            if (cc < a.C0) e[j] = act_load<DT>(a.src0, (size_t)so * a.C0 + cc);
+            else if (cc < C) e[j] = act_load<DT>(a.src1, (size_t)so * a.C1 + (cc - a.C0));
           }
         }
-        stg[it] = make_float4(e[0], e[1], e[2], e[3]);
+        stg[it] = Unit<DT>::pack(e);   // exact: the values came from the storage type
       }
     }
   };
 
   // GroupNorm affine + Swish in registers, convert, park in LDS buffer `buf`
   auto stage_store = [&](int g, int buf) {
-    const int c = g * (CPG * KC) + cvg * 4;
+    const int c = g * (CPG * KC) + cvg * CPU;
     unsigned char* dst = lds + buf * BUFB;
     const bool has_gn = a.gn_scale != nullptr && c < C;
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    float sc[CPU], sh[CPU];
+#pragma unroll
+    for (int j = 0; j < CPU; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
     auto load_affine = [&](int b) {
       const size_t gi = (size_t)b * C + c;
       if (!(a.stage_mode == 2)) {
-        const float4 s4 = *(const float4*)(a.gn_scale + gi);
-        const float4 h4 = *(const float4*)(a.gn_shift + gi);
-        sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
-        sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+#pragma unroll
+        for (int q = 0; q < CPU / 4; ++q) {
+          const float4 s4 = *(const float4*)(a.gn_scale + gi + 4 * q);
+          const float4 h4 = *(const float4*)(a.gn_shift + gi + 4 * q);
+          sc[4 * q] = s4.x; sc[4 * q + 1] = s4.y; sc[4 * q + 2] = s4.z; sc[4 * q + 3] = s4.w;
+          sh[4 * q] = h4.x; sh[4 * q + 1] = h4.y; sh[4 * q + 2] = h4.z; sh[4 * q + 3] = h4.w;
+        }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CPU; ++j) {
           sc[j] = (c + j < C) ? a.gn_scale[gi + j] : 0.f;
           sh[j] = (c + j < C) ? a.gn_shift[gi + j] : 0.f;
         }
@@ -331,33 +403,24 @@ __global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
       if (loff[it] >= 0) {
-        float4 v = stg[it];
+        float v[CPU];
+        Unit<DT>::unpack(stg[it], v);
         if (soff[it] >= 0 && c < C && !(a.ablate & 1)) {   // padding pixels stay exactly 0 (padded AFTER the activation)
           if (has_gn) {
             if (multi_img) load_affine(simg[it]);
-            v.x = v.x * sc[0] + sh[0];
-            v.y = v.y * sc[1] + sh[1];
-            v.z = v.z * sc[2] + sh[2];
-            v.w = v.w * sc[3] + sh[3];
+#pragma unroll
+            for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
           }
           if (a.swish) {
-            v.x = swish_f(v.x); v.y = swish_f(v.y); v.z = swish_f(v.z); v.w = swish_f(v.w);
+#pragma unroll
+            for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
           }
-          if ((a.stage_mode == 2)) {  // channels past C inside the last 4-group must stay 0
-            if (c + 1 >= C) v.y = 0.f;
-            if (c + 2 >= C) v.z = 0.f;
-            if (c + 3 >= C) v.w = 0.f;
+          if ((a.stage_mode == 2)) {  // channels past C inside the last unit must stay 0
+#pragma unroll
+            for (int j = 1; j < CPU; ++j) if (c + j >= C) v[j] = 0.f;
           }
         }
-        unsigned char* p = dst + loff[it];
-        if constexpr (IS_BF16) {
-          uint2 w;
-          w.x = pack_bf16x2(v.x, v.y);
-          w.y = pack_bf16x2(v.z, v.w);
-          *(uint2*)p = w;
-        } else {
-          *(float4*)p = v;
-        }
+        *(uint4*)(dst + loff[it]) = Unit<DT>::pack(v);
       }
     }
   };
@@ -416,15 +479,17 @@ __global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1
   DSX_STAMP(4);
 
   // ---- epilogue.  Accumulator layout (operands swapped): column = lane&31 = pixel of the row block,
-  // register r = channel (r&3) + 8*(r>>2) + 4*(lane>>5) of this wave's 32-channel block: every group of
-  // 4 registers is 4 consecutive channels -> float4 bias / FiLM / residual loads and float4 NHWC stores.
-  // Split-K slices write raw partial sums to their slab.  The GroupNorm statistics of the tensor being
+  // register r = channel 16*(lane>>5) + r of this wave's 32-channel block (the weight rows are packed
+  // permuted): 16 consecutive channels per lane -> 16-byte bias / FiLM / residual loads and NHWC stores.
+  // Split-K slices write raw partial sums to their fp32 slab.  The GroupNorm statistics of the tensor being
   // written (sum, sum of squares per channel over this wave's pixels) are accumulated in the same pass.
   if (a.ablate & 16) return;
-  const int nbase = (nt * WN + wn) * 32 + 4 * lh;
+  const int nbase = (nt * WN + wn) * 32 + 16 * lh;
   const bool partial = a.ksplit > 1;
-  float* outp = a.out + (partial ? (size_t)split * a.slab_stride : 0);
-  const bool vec = (a.Cout & 3) == 0 && (a.out_ld & 3) == 0 && (!a.resid || (a.resid_ld & 3) == 0);
+  const bool obf = IS_BF16 && a.out_bf16;
+  void* outp = partial ? (void*)((float*)a.out + (size_t)split * a.slab_stride) : a.out;
+  const int oal = obf ? 7 : 3, ral = IS_BF16 ? 7 : 3;   // 16-byte alignment of rows, in elements
+  const bool vec = (a.Cout & 15) == 0 && (a.out_ld & oal) == 0 && (!a.resid || (a.resid_ld & ral) == 0);
   // fused statistics are compiled only into the small-MB tiles: in the MB >= 4 tiles their registers
   // would cost a wave of occupancy (the host then falls back to k_chan_stats)
   constexpr bool STATS = MB <= 2;
@@ -441,59 +506,63 @@ __global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1
     const int tx = m & (TW - 1);
     const int ty = (m >> a.tw_log2) & (TH - 1);
     const int b = b0 + (m >> (a.tw_log2 + a.th_log2));
-    if (b >= a.B) continue;
+    if (b >= a.B || nbase >= a.Cout) continue;
     const size_t opix = ((size_t)b * a.Ho + (oy0 + ty)) * a.Wo + (ox0 + tx);
+    float x[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = nbase + 8 * j;
-      if (n >= a.Cout) continue;
-      float v[4] = {acc[mb][4 * j], acc[mb][4 * j + 1], acc[mb][4 * j + 2], acc[mb][4 * j + 3]};
-      if (vec) {
-        if (!partial) {
-          if (a.bias) { const float4 t = *(const float4*)(a.bias + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-          if (a.film) { const float4 t = *(const float4*)(a.film + (size_t)b * a.film_bs + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-          if (a.resid) { const float4 t = *(const float4*)(a.resid + opix * a.resid_ld + n); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+    for (int r = 0; r < 16; ++r) x[r] = acc[mb][r];
+    if (vec) {
+      if (!partial) {
+        if (a.bias) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float4 t = *(const float4*)(a.bias + nbase + 4 * j); x[4 * j] += t.x; x[4 * j + 1] += t.y; x[4 * j + 2] += t.z; x[4 * j + 3] += t.w; }
         }
-        *(float4*)(outp + opix * a.out_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
-        if (do_stats) {
+        if (a.film) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { s1[4 * j + k] += v[k]; s2[4 * j + k] += v[k] * v[k]; }
+          for (int j = 0; j < 4; ++j) { const float4 t = *(const float4*)(a.film + (size_t)b * a.film_bs + nbase + 4 * j); x[4 * j] += t.x; x[4 * j + 1] += t.y; x[4 * j + 2] += t.z; x[4 * j + 3] += t.w; }
         }
-      } else {
+        if (a.resid) {
+          const DT* rp = (const DT*)a.resid + opix * a.resid_ld + nbase;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (n + k >= a.Cout) break;
-          float x = v[k];
-          if (!partial) {
-            if (a.bias) x += a.bias[n + k];
-            if (a.film) x += a.film[(size_t)b * a.film_bs + n + k];
-            if (a.resid) x += a.resid[opix * a.resid_ld + n + k];
+          for (int q = 0; q < 16 / CPU; ++q) {
+            float t[CPU];
+            Unit<DT>::unpack(*(const uint4*)(rp + CPU * q), t);
+#pragma unroll
+            for (int j = 0; j < CPU; ++j) x[CPU * q + j] += t[j];
           }
-          outp[opix * a.out_ld + n + k] = x;
         }
       }
+      store16<true>(outp, opix * a.out_ld + nbase, x, obf, 16);
+      if (do_stats) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[r] += x[r]; s2[r] += x[r] * x[r]; }
+      }
+    } else {
+      const int valid = min(16, a.Cout - nbase);
+      if (!partial) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (r >= valid) break;
+          if (a.bias) x[r] += a.bias[nbase + r];
+          if (a.film) x[r] += a.film[(size_t)b * a.film_bs + nbase + r];
+          if (a.resid) x[r] += act_load<DT>(a.resid, opix * a.resid_ld + nbase + r);
+        }
+      }
+      store16<false>(outp, opix * a.out_ld + nbase, x, obf, valid);
     }
   }
   DSX_STAMP(5);
 
-  // ---- statistics: reduce over the 32 pixel lanes of each half-wave.  Four DPP steps inside the
-  // 16-lane rows (quad swaps, then row rotations) and one cross-row exchange; fixed order ->
-  // bitwise reproducible.  One partial row per (tile, wm): [b][chunk][channel][2] fp32.
+  // ---- statistics: reduce over the 32 pixel lanes of each half-wave (DPP butterfly inside the 16-lane
+  // rows, one cross-row exchange; fixed order -> bitwise reproducible).  One partial row per (tile, wm):
+  // [b][chunk][channel][2] fp32.
   if (do_stats) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s1[r] = row16_sum(s1[r]);
-      s2[r] = row16_sum(s2[r]);
-    }
-    // lane li < 16 keeps register li, then adds the other 16-lane row's copy (one bpermute each)
-    float w1 = s1[0], w2 = s2[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) { if ((li & 15) == r) { w1 = s1[r]; w2 = s2[r]; } }
+    float w1 = row16_fold(s1, lane), w2 = row16_fold(s2, lane);
     w1 += __shfl_xor(w1, 16, 64);
     w2 += __shfl_xor(w2, 16, 64);
     const int chunk = (tyi * a.tiles_x + txi) * WM + wm;   // partial row inside the image
     const int nch = a.tiles_x * a.tiles_y * WM;
-    const int n = (nt * WN + wn) * 32 + (li & 3) + 8 * (li >> 2) + 4 * lh;
+    const int n = nbase + row16_fold_reg(li);
     if (li < 16 && n < a.Cout) {
       float* p = a.stat_part + (((size_t)b0 * nch + chunk) * a.Cout + n) * 2;
       p[0] = w1; p[1] = w2;
@@ -550,10 +619,12 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   constexpr int LT = 64 * LW;                   // loader threads
   constexpr int S = 1;
   constexpr int KC = Chunk<DT>::KC;
-  constexpr int UPP = KC / 4;
+  constexpr int CPU = Unit<DT>::N;              // channels per 16-byte unit (HBM, raw ring and LDS image alike)
+  constexpr int ES = (int)sizeof(DT);
+  constexpr int UPP = KC / CPU;
   constexpr int UPG = UPP * CPG;
   constexpr int UPG_LOG2 = UPG == 16 ? 4 : (UPG == 8 ? 3 : 2);
-  constexpr int UB = 4 * (int)sizeof(DT);
+  constexpr int UB = 16;
   constexpr int PIXB = 64 * CPG + 16;
   constexpr int TAPS = KS * KS;
   constexpr int PAD = KS / 2;
@@ -673,10 +744,10 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     };
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.src0, 0, (int)min((long long)a.B * a.Hs * a.Ws * a.C0 * 4, 0x7fffffffLL), 0x00020000);
+        (void*)a.src0, 0, (int)min((long long)a.B * a.Hs * a.Ws * a.C0 * ES, 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.src1 ? a.src1 : a.src0), 0,
-        a.src1 ? (int)min((long long)a.B * a.Hs * a.Ws * a.C1 * 4, 0x7fffffffLL) : 0, 0x00020000);
+        a.src1 ? (int)min((long long)a.B * a.Hs * a.Ws * a.C1 * ES, 0x7fffffffLL) : 0, 0x00020000);
 
     int soffI[NIT], soffC[NIT];
     int b0I = 0, b0C = 0;
@@ -689,14 +760,14 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 
     // DMA the raw patch of item (tiI, gI) into ring slot `slot`; every wave issues exactly NIT instructions
     auto issue = [&](int slot) {
-      const int c = gI * (CPG * KC) + cvg * 4;
+      const int c = gI * (CPG * KC) + cvg * CPU;
       const bool first = gI * (CPG * KC) < a.C0;            // uniform: a group never straddles the sources
       const int cs = first ? a.C0 : a.C1;
-      const unsigned coff = c < C ? (unsigned)((first ? c : c - a.C0) * 4) : 0x80000000u;
+      const unsigned coff = c < C ? (unsigned)((first ? c : c - a.C0) * ES) : 0x80000000u;
       unsigned char* dst = raw_base + slot * RAWB + wave * 1024;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const unsigned vo = soffI[it] >= 0 ? (unsigned)soffI[it] * (unsigned)(cs * 4) + coff : 0x80000000u;
+        const unsigned vo = soffI[it] >= 0 ? (unsigned)soffI[it] * (unsigned)(cs * ES) + coff : 0x80000000u;
         auto ldst = (__attribute__((address_space(3))) void*)(dst + it * (LT * 16));
         if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, ldst, 16, vo, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, ldst, 16, vo, 0, 0, 0);
@@ -705,19 +776,24 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     };
     // raw slot -> GroupNorm affine + Swish -> MFMA image `buf` for item (tiC, gC)
     auto consume = [&](int slot, int buf) {
-      const int c = gC * (CPG * KC) + cvg * 4;
+      const int c = gC * (CPG * KC) + cvg * CPU;
       const unsigned src = lds0 + 2 * BUFB + 2 * AFFB + slot * RAWB + ltid * 16;
       const unsigned dst = lds0 + buf * BUFB;
       const bool has_gn = a.gn_scale != nullptr && c < C;
-      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+      float sc[CPU], sh[CPU];
+#pragma unroll
+      for (int j = 0; j < CPU; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
       if (has_gn) {
         // the compute waves parked this tile's scale/shift in LDS (an ordinary global load here would
         // make the compiler wait vmcnt(0) and drain the DMA ring)
         const unsigned af = lds0 + 2 * BUFB + (tiC & 1) * AFFB;
-        const f32x4_t s4 = lds_read_b128_asm(af + c * 4);
-        const f32x4_t h4 = lds_read_b128_asm(af + (C + c) * 4);
-        sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
-        sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+#pragma unroll
+        for (int q = 0; q < CPU / 4; ++q) {
+          const f32x4_t s4 = lds_read_b128_asm(af + (c + 4 * q) * 4);
+          const f32x4_t h4 = lds_read_b128_asm(af + (C + c + 4 * q) * 4);
+          sc[4 * q] = s4.x; sc[4 * q + 1] = s4.y; sc[4 * q + 2] = s4.z; sc[4 * q + 3] = s4.w;
+          sh[4 * q] = h4.x; sh[4 * q + 1] = h4.y; sh[4 * q + 2] = h4.z; sh[4 * q + 3] = h4.w;
+        }
       }
       f32x4_t rv[NIT];
 #pragma unroll
@@ -740,30 +816,22 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         if (loff[it] >= 0) {
-          float4 v = make_float4(rv[it].x, rv[it].y, rv[it].z, rv[it].w);
+          float v[CPU];
+          Unit<DT>::unpack(__builtin_bit_cast(uint4, rv[it]), v);
           if (soffC[it] >= 0 && c < C) {
             if (has_gn) {
-              v.x = v.x * sc[0] + sh[0];
-              v.y = v.y * sc[1] + sh[1];
-              v.z = v.z * sc[2] + sh[2];
-              v.w = v.w * sc[3] + sh[3];
+#pragma unroll
+              for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
             }
             if (a.swish) {
-              v.x = swish_f(v.x); v.y = swish_f(v.y); v.z = swish_f(v.z); v.w = swish_f(v.w);
+#pragma unroll
+              for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
             }
           } else {
-            v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < CPU; ++j) v[j] = 0.f;
           }
-          const unsigned p = dst + loff[it];
-          if constexpr (IS_BF16) {
-            u32x2_t w;
-            w.x = pack_bf16x2(v.x, v.y);
-            w.y = pack_bf16x2(v.z, v.w);
-            lds_write_b64_asm(p, w);
-          } else {
-            f32x4_t w = {v.x, v.y, v.z, v.w};
-            lds_write_b128_asm(p, w);
-          }
+          lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, Unit<DT>::pack(v)));
         }
       }
       if (++gC == G) { gC = 0; ++tiC; if (tiC < ntile) make_plan(tiC, soffC, b0C); }
@@ -840,7 +908,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 
   constexpr bool STATS = MB <= 2;
   const bool do_stats = STATS && a.stat_part != nullptr;
-  const int nbase = blk * 32 + 4 * lh;
+  const int nbase = blk * 32 + 16 * lh;         // this lane's 16 consecutive channels
 
   // Tile walk without divisions: (tx, ty, image) of tile p0 + k*wpn, advanced by the decomposed stride.
   struct TilePos { int tx, ty, b; };
@@ -879,28 +947,32 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   // epilogue (right after its own operands were consumed): the loads then have the rest of that epilogue
   // plus the 18 ring steps to land before an in-order vmcnt wait of the weight ring can trip over them.
   // Bias is fetched once (the workgroup never changes its N tile).  Missing operands stay 0.0f: exact.
+  constexpr int NR = 16 / CPU;   // 16-byte pieces of a lane's 16 residual values
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 biasv[4], filmv[4], residv[MB][4], affv[2];
+  float4 biasv[4], filmv[4], affv[2];
+  uint4 residv[MB][NR];          // storage type; all-zero bits are 0.0 in both
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    biasv[j] = a.bias ? *(const float4*)(a.bias + nbase + 8 * j) : zero4;
+    biasv[j] = a.bias ? *(const float4*)(a.bias + nbase + 4 * j) : zero4;
     filmv[j] = zero4;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) residv[mb][j] = zero4;
   }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) residv[mb][q] = make_uint4(0u, 0u, 0u, 0u);
   affv[0] = affv[1] = zero4;
   // t: the tile whose epilogue will use the operands; b_aff: image of the tile two after it
   auto prefetch_epilogue = [&](const TilePos& t, bool want_aff, int b_aff) {
     if (a.film) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) filmv[j] = *(const float4*)(a.film + (size_t)t.b * a.film_bs + nbase + 8 * j);
+      for (int j = 0; j < 4; ++j) filmv[j] = *(const float4*)(a.film + (size_t)t.b * a.film_bs + nbase + 4 * j);
     }
     if (a.resid) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const float* rp = a.resid + out_pixel(t, mb) * a.resid_ld + nbase;
+        const DT* rp = (const DT*)a.resid + out_pixel(t, mb) * a.resid_ld + nbase;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) residv[mb][j] = *(const float4*)(rp + 8 * j);
+        for (int q = 0; q < NR; ++q) residv[mb][q] = *(const uint4*)(rp + CPU * q);
       }
     }
     if (want_aff && a.gn_scale != nullptr && tid * 4 < C) {
@@ -947,7 +1019,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     g = 0;
 
     // ---- tile finished: epilogue (+ fused statistics).  Accumulator register r of a lane is channel
-    //      (r & 3) + 8 * (r >> 2) + 4 * lh of the wave's 32-channel block, for the lane's pixel.
+    //      16 * lh + r of the wave's 32-channel block, for the lane's pixel (see store16).
     // scale/shift of tile ti+2 -> LDS (tile ti+1's is already there; slot parity of ti+2 == ti, whose use has ended)
     if (a.gn_scale != nullptr && ti + 2 < ntile && tid * 4 < C) {
       float* dst = aff_base + (size_t)(ti & 1) * (AFFB / 4);
@@ -956,15 +1028,24 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     }
     // reference order: conv -> + bias -> + FiLM -> + residual
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MB; ++mb) {
+      float rs[16];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        float t[CPU];
+        Unit<DT>::unpack(residv[mb][q], t);
+#pragma unroll
+        for (int j = 0; j < CPU; ++j) rs[CPU * q + j] = t[j];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 tb = biasv[j], tf = filmv[j], tr = residv[mb][j];
-        acc[mb][4 * j + 0] = ((acc[mb][4 * j + 0] + tb.x) + tf.x) + tr.x;
-        acc[mb][4 * j + 1] = ((acc[mb][4 * j + 1] + tb.y) + tf.y) + tr.y;
-        acc[mb][4 * j + 2] = ((acc[mb][4 * j + 2] + tb.z) + tf.z) + tr.z;
-        acc[mb][4 * j + 3] = ((acc[mb][4 * j + 3] + tb.w) + tf.w) + tr.w;
+        const float4 tb = biasv[j], tf = filmv[j];
+        acc[mb][4 * j + 0] = ((acc[mb][4 * j + 0] + tb.x) + tf.x) + rs[4 * j + 0];
+        acc[mb][4 * j + 1] = ((acc[mb][4 * j + 1] + tb.y) + tf.y) + rs[4 * j + 1];
+        acc[mb][4 * j + 2] = ((acc[mb][4 * j + 2] + tb.z) + tf.z) + rs[4 * j + 2];
+        acc[mb][4 * j + 3] = ((acc[mb][4 * j + 3] + tb.w) + tf.w) + rs[4 * j + 3];
       }
+    }
     DSX_STAMP_T(61, tid == 0 && ti == 1);
     // the operand registers are free again: fetch the next tile's (and the scale/shift of tile ti+3)
     const TilePos done = cur;
@@ -977,10 +1058,12 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      float* op = a.out + out_pixel(done, mb) * a.out_ld + nbase;
+      {
+        float x[16];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *(float4*)(op + 8 * j) = make_float4(acc[mb][4 * j], acc[mb][4 * j + 1], acc[mb][4 * j + 2], acc[mb][4 * j + 3]);
+        for (int r = 0; r < 16; ++r) x[r] = acc[mb][r];
+        store16<true>(a.out, out_pixel(done, mb) * a.out_ld + nbase, x, IS_BF16, 16);   // host: out is in the storage type
+      }
       if constexpr (STATS) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s1[r] += acc[mb][r]; s2[r] += acc[mb][r] * acc[mb][r]; }
@@ -996,8 +1079,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       w2 += __shfl_xor(w2, 16, 64);
       const int chunk = (done.ty * a.tiles_x + done.tx) * WM + wm;
       const int nch = per_img * WM;
-      const int r = row16_fold_reg(li);
-      const int n = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int n = nbase + row16_fold_reg(li);
       if (li < 16) {
         float* pp = a.stat_part + (((size_t)done.b * nch + chunk) * a.Cout + n) * 2;
         pp[0] = w1; pp[1] = w2;
@@ -1035,7 +1117,8 @@ static constexpr int max_px(int tile, int ks, int stride) {
   return stride == 2 ? 400 : (bm == 256 ? 400 : (bm == 128 ? 220 : 144));
 }
 static constexpr int max_it(int dtype, int tile, int ks, int stride) {
-  const int upg = (dtype == 1 ? 8 : 4) * conv_cpg(ks);
+  const int upg = 4 * conv_cpg(ks);   // 16-byte units per pixel per group, either storage type
+  (void)dtype;
   return (max_px(tile, ks, stride) * upg + 255) / 256;
 }
 
@@ -1122,7 +1205,8 @@ static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activati
 }
 static constexpr int kWsLoaderWaves = 4;
 static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units per loader thread per group
-  const int upg = (dtype == 1 ? 8 : 4) * conv_cpg(ks);
+  const int upg = 4 * conv_cpg(ks);
+  (void)dtype;
   return (max_px(tile, ks, 1) * upg + kWsLoaderWaves * 64 - 1) / (kWsLoaderWaves * 64);
 }
 size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
@@ -1135,7 +1219,9 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   const size_t total = 2 * bufb + 2 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb;
   if (a.tb_log2 != 0 || a.kchunks / conv_cpg(ks) < 2) return 0;   // one image per tile, >= 2 channel groups
   // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
-  if (a.Cout % (32 * kTiles[tile].WN) != 0 || (a.out_ld & 3) != 0 || (a.resid_ld & 3) != 0 || a.C0 + a.C1 > 1024) return 0;
+  const int al = dtype == 1 ? 7 : 3;   // 16-byte rows in elements of the storage type
+  if (a.Cout % (32 * kTiles[tile].WN) != 0 || (a.out_ld & al) != 0 || (a.resid_ld & al) != 0 || a.C0 + a.C1 > 1024) return 0;
+  if (dtype == 1 && !(a.act_bf16 && a.out_bf16)) return 0;   // this kernel reads and writes the storage type only
   return total <= 160 * 1024 ? total : 0;
 }
 
@@ -1223,7 +1309,8 @@ __global__ void k_conv_naive(const NaiveConvArgs na) {
         const size_t so = ((size_t)b * a.Hs + sy) * a.Ws + sx;
         const float* w = na.w + (((size_t)n * na.ks + dy) * na.ks + dx) * C;
         for (int c = 0; c < C; ++c) {
-          float v = c < a.C0 ? a.src0[so * a.C0 + c] : a.src1[so * a.C1 + (c - a.C0)];
+          float v = c < a.C0 ? (a.act_bf16 ? act_load<__bf16>(a.src0, so * a.C0 + c) : act_load<float>(a.src0, so * a.C0 + c))
+                             : (a.act_bf16 ? act_load<__bf16>(a.src1, so * a.C1 + (c - a.C0)) : act_load<float>(a.src1, so * a.C1 + (c - a.C0)));
           if (a.gn_scale) v = v * a.gn_scale[(size_t)b * C + c] + a.gn_shift[(size_t)b * C + c];
           if (a.swish) v = swish_f(v);
           acc = fmaf(v, w[c], acc);
@@ -1233,9 +1320,9 @@ __global__ void k_conv_naive(const NaiveConvArgs na) {
     const size_t opix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
     float v = acc + (a.bias ? a.bias[n] : 0.f);
     if (a.film) v += a.film[(size_t)b * a.film_bs + n];
-    if (a.resid) v += a.resid[opix * a.resid_ld + n];
+    if (a.resid) v += a.act_bf16 ? act_load<__bf16>(a.resid, opix * a.resid_ld + n) : act_load<float>(a.resid, opix * a.resid_ld + n);
     if (na.sigmoid_out) v = 1.0f / (1.0f + __expf(-v));
-    a.out[opix * a.out_ld + n] = v;
+    act_store(a.out, opix * a.out_ld + n, v, a.out_bf16 != 0);
   }
 }
 

@@ -14,8 +14,10 @@ namespace dsx {
 //   Implicit GEMM on MFMA: M = output pixels, N = Cout, K = taps x Cin.
 // ---------------------------------------------------------------------------
 struct ConvArgs {
-  const float* src0;
-  const float* src1;
+  const void* src0;       // NHWC activations in the storage type: fp32, or bf16 when act_bf16
+  const void* src1;
+  int act_bf16;           // src0 / src1 / resid hold bf16 (the bf16-MFMA build stores activations in bf16)
+  int out_bf16;           // out holds bf16 (0 for split-K slabs and the network's final output)
   int C0, C1;             // channels per source (C1 == 0: single source)
   int B, Hs, Ws;          // source spatial size (before the optional upsample)
   int up;                 // 1: nearest x2 upsample fused into the patch load
@@ -24,15 +26,16 @@ struct ConvArgs {
   const float* gn_shift;
   int has_gn;             // GroupNorm affine fused (== gn_scale != nullptr once the workspace exists)
   int swish;              // v = v*sigmoid(v) after the affine
-  int stage_mode;         // 0: sources aligned to the channel group (buffer loads); 1: float4 loads with
-                          // per-lane source select; 2: channel counts not multiples of 4 (per-element loads)
+  int stage_mode;         // 0: sources aligned to the channel group (buffer loads); 1: 16-byte loads with
+                          // per-lane source select; 2: channel counts not multiples of the 16-byte unit
+                          // (4 fp32 / 8 bf16 channels): per-element loads
   const void* wpack;      // MFMA-fragment-ordered weights (fp32 or bf16)
   const float* bias;      // [Cout] or nullptr
   const float* film;      // film[b*film_bs + n] or nullptr (FiLM / time-embedding add)
   int film_bs;
-  const float* resid;     // [B][Ho][Wo][resid_ld] or nullptr
+  const void* resid;      // [B][Ho][Wo][resid_ld] (storage type) or nullptr
   int resid_ld;
-  float* out;             // [B][Ho][Wo][out_ld]
+  void* out;              // [B][Ho][Wo][out_ld]
   int out_ld;
   int Cout;
   int nblocks;            // ceil(Cout/32)
@@ -84,7 +87,7 @@ hipError_t launch_conv_naive(const NaiveConvArgs& a, hipStream_t st);
 // ---------------------------------------------------------------------------
 // per-(image, pixel-chunk, channel) partial {sum, sumsq} in double:
 //   part[((b*nchunk + ch)*C + c)*2 + {0,1}]
-hipError_t launch_chan_stats(const float* x, int B, int HW, int C, int nchunk, double* part,
+hipError_t launch_chan_stats(const void* x, int bf16, int B, int HW, int C, int nchunk, double* part,
                              hipStream_t st);
 // GroupNorm of the concatenation of (t0, t1) -> scale/shift[b][C0+C1]
 struct GnFinArgs {
@@ -124,10 +127,11 @@ hipError_t launch_temb(const TembArgs& a, hipStream_t st);
 // attention (single head, d = C):  S = QK^T/sqrt(C); P = softmax(S); O = PV
 // ---------------------------------------------------------------------------
 struct BgemmArgs {
-  const float* A; int lda; long long sA;   // A[bt][m][k]
-  const float* Bm; int ldb; long long sB;  // b_kmajor=0: B[bt][n][k]; 1: B[bt][k][n]
+  const void* A; int lda; long long sA;    // A[bt][m][k]            (strides in elements)
+  const void* Bm; int ldb; long long sB;   // b_kmajor=0: B[bt][n][k]; 1: B[bt][k][n]
   int b_kmajor;
-  float* Cm; int ldc; long long sC;
+  void* Cm; int ldc; long long sC;
+  int a_bf16, b_bf16, c_bf16;              // element type of each matrix (0: fp32)
   int M, N, K, batch;
   float div;                               // C = acc / div
 };
@@ -137,8 +141,9 @@ struct SplitKReduceArgs {
   const float* slab; int nsplit; long long slab_stride;
   long long M; int N; int HW;            // b = m / HW
   const float* bias; const float* film; int film_bs;
-  const float* resid; int resid_ld;
-  float* out;
+  const void* resid; int resid_ld;
+  void* out;
+  int act_bf16;                          // resid and out hold bf16
 };
 hipError_t launch_splitk_reduce(const SplitKReduceArgs& a, hipStream_t st);
 hipError_t launch_softmax_rows(float* S, long long rows, int L, hipStream_t st);
@@ -147,12 +152,14 @@ hipError_t launch_softmax_rows(float* S, long long rows, int L, hipStream_t st);
 // layout, sampler update, RNG, tiling
 // ---------------------------------------------------------------------------
 // dst[b][hw][c] = src[(b*ctot + coff + c)*HW + hw]   (channel slice of an NCHW tensor -> NHWC)
-hipError_t launch_nchw_slice_to_nhwc(const float* src, float* dst, int B, int C, int ctot, int coff, int HW,
-                                     hipStream_t st);
+hipError_t launch_nchw_slice_to_nhwc(const float* src, void* dst, int dst_bf16, int B, int C, int ctot, int coff,
+                                     int HW, hipStream_t st);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, hipStream_t st);
 
 struct UpdateArgs {
-  float* x;               // state, NHWC [B][H][W][C]
+  float* x;               // state, NHWC [B][H][W][C], always fp32
+  void* x_act;            // the first conv's copy of the state in the activation storage type (bf16 build),
+                          // or nullptr when the conv reads `x` itself
   const float* net;       // UNet output, NHWC
   const float* noise;     // nullptr -> Philox; else [steps][B][C][H][W] (NCHW, reference draw order)
   unsigned long long seed;

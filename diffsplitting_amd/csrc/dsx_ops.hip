@@ -31,13 +31,33 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // partial sums are kept in double so the later E[x^2]-E[x]^2 is safe.
 // part[((b*nchunk + ch)*C + c)*2 + {0:sum, 1:sumsq}]
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x, int HW, int C,
+__device__ __forceinline__ float4 load4_act(const void* base, size_t i, int bf16) {   // 4 consecutive elements
+  if (bf16) {
+    const uint2 r = *(const uint2*)((const unsigned short*)base + i);
+    return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                       __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+  }
+  return *(const float4*)((const float*)base + i);
+}
+__device__ __forceinline__ float load1_act(const void* base, size_t i, int bf16) {
+  return bf16 ? __builtin_bit_cast(float, (unsigned)((const unsigned short*)base)[i] << 16) : ((const float*)base)[i];
+}
+__device__ __forceinline__ void store1_act(void* base, size_t i, float v, int bf16) {
+  if (bf16) {
+    const __bf16 h = (__bf16)v;   // RNE
+    ((unsigned short*)base)[i] = __builtin_bit_cast(unsigned short, h);
+  } else {
+    ((float*)base)[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chan_stats(const void* __restrict__ x, int bf16, int HW, int C,
                                                     int nchunk, double* __restrict__ part) {
   __shared__ double red[256 * 8];
   const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
   const int CV = C >> 2;  // float4 columns
   const int p0 = (int)((long long)HW * ch / nchunk), p1 = (int)((long long)HW * (ch + 1) / nchunk);
-  const float* xb = x + (size_t)b * HW * C;
+  const size_t xb = (size_t)b * HW * C;
   for (int cv0 = 0; cv0 < CV; cv0 += 256) {
     const int cols = min(256, CV - cv0);   // columns in this pass
     const int rows = 256 / cols;           // pixel lanes per column (>=1)
@@ -45,7 +65,7 @@ __global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x,
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (rl < rows) {
       for (int p = p0 + rl; p < p1; p += rows) {
-        const float4 v = *(const float4*)(xb + (size_t)p * C + (cv0 + col) * 4);
+        const float4 v = load4_act(x, xb + (size_t)p * C + (cv0 + col) * 4, bf16);
         s[0] += v.x; q[0] += (double)v.x * v.x;
         s[1] += v.y; q[1] += (double)v.y * v.y;
         s[2] += v.z; q[2] += (double)v.z * v.z;
@@ -70,9 +90,9 @@ __global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x,
   }
 }
 
-hipError_t launch_chan_stats(const float* x, int B, int HW, int C, int nchunk, double* part,
+hipError_t launch_chan_stats(const void* x, int bf16, int B, int HW, int C, int nchunk, double* part,
                              hipStream_t st) {
-  hipLaunchKernelGGL(k_chan_stats, dim3((unsigned)(B * nchunk)), dim3(256), 0, st, x, HW, C, nchunk, part);
+  hipLaunchKernelGGL(k_chan_stats, dim3((unsigned)(B * nchunk)), dim3(256), 0, st, x, bf16, HW, C, nchunk, part);
   return hipGetLastError();
 }
 
@@ -220,27 +240,35 @@ __global__ __launch_bounds__(256) void k_bgemm(const BgemmArgs a) {
   const int bt = blockIdx.x / (tiles_m * tiles_n);
   const int t = blockIdx.x % (tiles_m * tiles_n);
   const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
-  const float* A = a.A + (size_t)bt * a.sA;
-  const float* Bm = a.Bm + (size_t)bt * a.sB;
-  float* Cm = a.Cm + (size_t)bt * a.sC;
+  const size_t A0 = (size_t)bt * a.sA, B0 = (size_t)bt * a.sB, C0 = (size_t)bt * a.sC;   // element offsets
+  // 8 consecutive elements starting at element index i (16-byte aligned when `al`)
+  auto load8 = [&](const void* base, int bf16, size_t i, bool al, int nvalid, float4 out[2]) {
+    if (al && nvalid >= 8) {
+      if (bf16) {
+        const uint4 r = *(const uint4*)((const unsigned short*)base + i);
+        out[0] = make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                             __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+        out[1] = make_float4(__builtin_bit_cast(float, r.z << 16), __builtin_bit_cast(float, r.z & 0xffff0000u),
+                             __builtin_bit_cast(float, r.w << 16), __builtin_bit_cast(float, r.w & 0xffff0000u));
+      } else {
+        out[0] = *(const float4*)((const float*)base + i);
+        out[1] = *(const float4*)((const float*)base + i + 4);
+      }
+    } else {
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = j < nvalid ? load1_act(base, i + j, bf16) : 0.f;
+      out[0] = make_float4(e[0], e[1], e[2], e[3]);
+      out[1] = make_float4(e[4], e[5], e[6], e[7]);
+    }
+  };
 
   // row-major [row][k] operand (A, or B when !b_kmajor): thread -> (row = tid/4, 8 consecutive k)
-  auto load_rk = [&](const float* base, int ld, int row0, int rows, int k0, float4 out[2]) {
+  auto load_rk = [&](const void* base, int bf16, size_t off0, int ld, int row0, int rows, int k0, float4 out[2]) {
     const int r = tid >> 2, kk = (tid & 3) * 8;
     out[0] = out[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < rows) {
-      const float* p = base + (size_t)(row0 + r) * ld + k0 + kk;
-      if (k0 + kk + 7 < a.K && (ld & 3) == 0) {
-        out[0] = *(const float4*)p;
-        out[1] = *(const float4*)(p + 4);
-      } else {
-        float e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = (k0 + kk + j < a.K) ? p[j] : 0.f;
-        out[0] = make_float4(e[0], e[1], e[2], e[3]);
-        out[1] = make_float4(e[4], e[5], e[6], e[7]);
-      }
-    }
+    if (row0 + r < rows)
+      load8(base, bf16, off0 + (size_t)(row0 + r) * ld + k0 + kk, ((ld | off0) & 7) == 0, a.K - (k0 + kk), out);
   };
   auto store_rk = [&](float* S, const float4 v[2]) {
     const int r = tid >> 2, kk = (tid & 3) * 8;
@@ -251,21 +279,10 @@ __global__ __launch_bounds__(256) void k_bgemm(const BgemmArgs a) {
   // k-major B[k][n]: thread -> (k = tid/8, 8 consecutive n), stored transposed as Bs[n][k]
   auto load_kn = [&](int k0, float4 out[2]) {
     const int kk = tid >> 3, nn = (tid & 7) * 8;
-    float e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = 0.f;
-    if (k0 + kk < a.K) {
-      const float* p = Bm + (size_t)(k0 + kk) * a.ldb + n0 + nn;
-      if (n0 + nn + 7 < a.N && (a.ldb & 3) == 0) {
-        const float4 u = *(const float4*)p, w = *(const float4*)(p + 4);
-        e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w; e[4] = w.x; e[5] = w.y; e[6] = w.z; e[7] = w.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (n0 + nn + j < a.N) e[j] = p[j];
-      }
-    }
-    out[0] = make_float4(e[0], e[1], e[2], e[3]);
-    out[1] = make_float4(e[4], e[5], e[6], e[7]);
+    out[0] = out[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 + kk < a.K)
+      load8(a.Bm, a.b_bf16, B0 + (size_t)(k0 + kk) * a.ldb + n0 + nn, ((a.ldb | B0 | (size_t)n0) & 7) == 0,
+            a.N - (n0 + nn), out);
   };
   auto store_kn = [&](const float4 v[2]) {
     const int kk = tid >> 3, nn = (tid & 7) * 8;
@@ -279,15 +296,15 @@ __global__ __launch_bounds__(256) void k_bgemm(const BgemmArgs a) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   float4 ra[2], rb[2];
-  load_rk(A, a.lda, m0, a.M, 0, ra);
-  if (!a.b_kmajor) load_rk(Bm, a.ldb, n0, a.N, 0, rb); else load_kn(0, rb);
+  load_rk(a.A, a.a_bf16, A0, a.lda, m0, a.M, 0, ra);
+  if (!a.b_kmajor) load_rk(a.Bm, a.b_bf16, B0, a.ldb, n0, a.N, 0, rb); else load_kn(0, rb);
   for (int k0 = 0; k0 < a.K; k0 += KC) {
     store_rk(As, ra);
     if (!a.b_kmajor) store_rk(Bs, rb); else store_kn(rb);
     __syncthreads();
     if (k0 + KC < a.K) {   // prefetch the next chunk while this one is multiplied
-      load_rk(A, a.lda, m0, a.M, k0 + KC, ra);
-      if (!a.b_kmajor) load_rk(Bm, a.ldb, n0, a.N, k0 + KC, rb); else load_kn(k0 + KC, rb);
+      load_rk(a.A, a.a_bf16, A0, a.lda, m0, a.M, k0 + KC, ra);
+      if (!a.b_kmajor) load_rk(a.Bm, a.b_bf16, B0, a.ldb, n0, a.N, k0 + KC, rb); else load_kn(k0 + KC, rb);
     }
 #pragma unroll
     for (int s = 0; s < KC / 2; ++s) {
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(256) void k_bgemm(const BgemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < a.M) Cm[(size_t)m * a.ldc + n] = acc[r] / a.div;
+      if (m < a.M) store1_act(a.Cm, C0 + (size_t)m * a.ldc + n, acc[r] / a.div, a.c_bf16);
     }
   }
 }
@@ -324,8 +341,8 @@ __global__ void k_splitk_reduce(const SplitKReduceArgs a) {
     for (int s = 0; s < a.nsplit; ++s) v += a.slab[(size_t)s * a.slab_stride + i];
     if (a.bias) v += a.bias[n];
     if (a.film) v += a.film[(size_t)(m / a.HW) * a.film_bs + n];
-    if (a.resid) v += a.resid[(size_t)m * a.resid_ld + n];
-    a.out[i] = v;
+    if (a.resid) v += load1_act(a.resid, (size_t)m * a.resid_ld + n, a.act_bf16);
+    store1_act(a.out, (size_t)i, v, a.act_bf16);
   }
 }
 hipError_t launch_splitk_reduce(const SplitKReduceArgs& a, hipStream_t st) {
@@ -358,14 +375,14 @@ hipError_t launch_softmax_rows(float* S, long long rows, int L, hipStream_t st) 
 // ---------------------------------------------------------------------------
 // layout conversion at the boundary (the reference passes NCHW)
 // ---------------------------------------------------------------------------
-__global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int C, int ctot,
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, void* __restrict__ dst, int dst_bf16, int C, int ctot,
                                int coff, int HW, long long total) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const long long p = i / C;
     const long long b = p / HW, hw = p % HW;
-    dst[i] = src[(b * ctot + coff + c) * HW + hw];
+    store1_act(dst, (size_t)i, src[(b * ctot + coff + c) * HW + hw], dst_bf16);
   }
 }
 __global__ void k_nhwc_to_nchw(const float* __restrict__ src, float* __restrict__ dst, int C, int HW,
@@ -383,10 +400,10 @@ static unsigned grid_for(long long total) {
   long long g = (total + 255) / 256;
   return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
-hipError_t launch_nchw_slice_to_nhwc(const float* src, float* dst, int B, int C, int ctot, int coff, int HW,
-                                     hipStream_t st) {
+hipError_t launch_nchw_slice_to_nhwc(const float* src, void* dst, int dst_bf16, int B, int C, int ctot, int coff,
+                                     int HW, hipStream_t st) {
   const long long total = (long long)B * C * HW;
-  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(grid_for(total)), dim3(256), 0, st, src, dst, C, ctot, coff, HW, total);
+  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(grid_for(total)), dim3(256), 0, st, src, dst, dst_bf16, C, ctot, coff, HW, total);
   return hipGetLastError();
 }
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, hipStream_t st) {
@@ -484,7 +501,9 @@ __global__ void k_update(const UpdateArgs a) {
         if (a.clip) o = fminf(fmaxf(o, -1.0f), 1.0f);
       }
       const float mean = __fadd_rn(__fmul_rn(c1, o), __fmul_rn(c2, x));
-      a.x[i] = __fadd_rn(mean, __fmul_rn(zz, sg));
+      const float xn = __fadd_rn(mean, __fmul_rn(zz, sg));
+      a.x[i] = xn;
+      if (a.x_act) store1_act(a.x_act, (size_t)i, xn, 1);
     }
   }
 }

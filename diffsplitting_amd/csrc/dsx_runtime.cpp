@@ -328,7 +328,10 @@ static void pack_conv(const float* w, int cout, int cin, int ks, int dtype, std:
       for (int tap = 0; tap < taps; ++tap)
         for (int fs = 0; fs < 2; ++fs)
           for (int lane = 0; lane < 64; ++lane) {
-            const int i = lane & 31, h = lane >> 5, n = nb * 32 + i;
+            // MFMA A row i = q + 8*j + 4*hh carries output channel 16*hh + 4*j + q of the block, so that a
+            // lane's 16 accumulator registers are 16 consecutive channels (dsx_conv.hip, store16)
+            const int i = lane & 31, h = lane >> 5;
+            const int n = nb * 32 + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
             char* p = dst.data() + ((((size_t)(nb * kchunks + kc) * taps + tap) * 2 + fs) * 64 + lane) * 16;
             for (int j = 0; j < EPL; ++j) {
               const int c = kc * KC + (KC / 2) * fs + EPL * h + j;
@@ -463,9 +466,11 @@ extern "C" double dsx_model_flops(const dsx_model* m, int H, int W) {
 namespace {
 
 struct Tensor {
-  float* p = nullptr;
+  void* p = nullptr;       // NHWC, fp32 or (bf16 build) bf16
   int C = 0, H = 0, W = 0;
   int id = -1;             // index into dsx_exec::stats (copies of a Tensor share it)
+  bool bf16 = false;
+  char* at(size_t elem) const { return (char*)p + elem * (bf16 ? 2 : 4); }
 };
 struct StatInfo {          // GroupNorm partial sums of one tensor, produced at most once
   void* part = nullptr;    // double [B][nchunk][C][2] (k_chan_stats) or float (fused into the conv epilogue)
@@ -497,6 +502,7 @@ struct dsx_exec {
   std::vector<StatInfo> stats;
   // fixed buffers
   Tensor in_cond, in_x, out;   // NHWC
+  float* x_state = nullptr;    // sampler state, NHWC fp32 (== in_x.p unless activations are stored in bf16)
   float* film = nullptr;       // [B][F]
   float* time_buf = nullptr;   // [B] direct time values
   int* step_ctr = nullptr;
@@ -537,10 +543,12 @@ static char* ws_alloc(dsx_exec* ex, size_t bytes) {
   if (ex->ws_used > ex->ws_bytes) ex->overflow = true;   // sizing and planning passes diverged: reported by build_plan
   return ex->ws + off;
 }
-static Tensor new_tensor(dsx_exec* ex, int C, int H, int W) {
+// activations are stored in the MFMA operand type (bf16 build: bf16); `f32` forces fp32 (network output)
+static Tensor new_tensor(dsx_exec* ex, int C, int H, int W, bool f32 = false) {
   Tensor t;
   t.C = C; t.H = H; t.W = W;
-  t.p = (float*)ws_alloc(ex, (size_t)ex->B * H * W * C * sizeof(float));
+  t.bf16 = ex->m->dtype == 1 && !f32;
+  t.p = ws_alloc(ex, (size_t)ex->B * H * W * C * (t.bf16 ? 2 : 4));
   t.id = (int)ex->stats.size();
   ex->stats.push_back(StatInfo());
   return t;
@@ -626,7 +634,7 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
     if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
     const long long grid = (long long)c.m_tiles * c.n_tiles;
     long long eff = grid;
-    if (splitk_on && grid < min_grid && kgroups >= 4 && (a.Cout % 4) == 0 && a.out_ld == a.Cout) {
+    if (splitk_on && grid < min_grid && kgroups >= 4 && (a.Cout % 16) == 0 && a.out_ld == a.Cout) {
       const int want = (int)((min_grid + grid - 1) / grid);
       int S = std::min(want, kgroups / 2);  // at least two channel groups per slice
       const int gps = (kgroups + S - 1) / S;
@@ -656,7 +664,7 @@ struct ConvSpec {
   bool has_resid = false;
   bool swish = false;
   const float* film = nullptr; int film_bs = 0;
-  const float* resid = nullptr; int resid_ld = 0;
+  const void* resid = nullptr; int resid_ld = 0;
   Tensor out;
   bool want_stats = false;   // a GroupNorm will read `out`: produce its statistics in the epilogue
 };
@@ -669,9 +677,12 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   a.Ho = s.out.H; a.Wo = s.out.W;
   a.gn_scale = s.gn_scale; a.gn_shift = s.gn_shift; a.swish = s.swish ? 1 : 0;
   a.has_gn = s.has_gn ? 1 : 0;
+  a.act_bf16 = ex->m->dtype == 1 ? 1 : 0;
+  a.out_bf16 = s.out.bf16 ? 1 : 0;
   {
     const int gw = conv_chunk_multiple(s.w->ks) * (ex->m->dtype == 1 ? 32 : 16);  // channels per staged group
-    a.stage_mode = ((a.C0 & 3) || (a.C1 & 3)) ? 2 : ((a.C1 == 0 || a.C0 % gw == 0) ? 0 : 1);
+    const int um = ex->m->dtype == 1 ? 7 : 3;                                       // channels per 16-byte unit - 1
+    a.stage_mode = ((a.C0 & um) || (a.C1 & um)) ? 2 : ((a.C1 == 0 || a.C0 % gw == 0) ? 0 : 1);
   }
   a.wpack = s.w->pack; a.bias = s.w->bias;
   a.film = s.film; a.film_bs = s.film_bs;
@@ -685,8 +696,8 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   ex->launches++;
   static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
   if (fuse_stats && s.want_stats && mfma_ok && conv_tile_fuses_stats(tile) && a.ksplit == 1 && a.tb_log2 == 0 &&
-      (a.Cout & 3) == 0 &&
-      a.out_ld == a.Cout && (a.resid_ld & 3) == 0) {
+      (a.Cout & 15) == 0 &&
+      a.out_ld == a.Cout && (a.resid_ld & 7) == 0) {
     StatInfo& si = ex->stats[s.out.id];
     si.nchunk = a.tiles_x * a.tiles_y * conv_tile_wm(tile);
     si.part = ws_alloc(ex, (size_t)a.B * si.nchunk * a.Cout * 2 * sizeof(float));
@@ -717,23 +728,25 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   const double cin = a.C0 + a.C1;
   const double flops = 2.0 * npix * a.Cout * cin * ks * ks;
   const double wbytes = (double)a.Cout * cin * ks * ks * (dtype == 1 ? 2 : 4);
-  const double bytes = 4.0 * ((double)a.B * a.Hs * a.Ws * cin + npix * a.Cout * (a.resid ? 2 : 1)) + wbytes;
+  const double esz = dtype == 1 ? 2.0 : 4.0;   // activation element size in HBM
+  const double bytes = esz * ((double)a.B * a.Hs * a.Ws * cin + npix * a.Cout * (a.resid ? 1 : 0)) +
+                       (a.out_bf16 ? 2.0 : 4.0) * npix * a.Cout + wbytes;
   if (mfma_ok) {
     const ConvTileInfo ti = conv_tile_info(tile);
     const std::string d = fmt("conv%dx%d%s%s %d->%d @%dx%d tile%dx%d", ks, ks, stride == 2 ? "s2" : "",
                               a.up ? "up" : "", (int)cin, a.Cout, a.Ho, a.Wo, ti.BM, ti.BN);
     if (a.ksplit > 1) {
-      ConvArgs p = a;  // slices write raw sums into slabs; a reduce launch applies the epilogue
-      p.out = slab;
+      ConvArgs p = a;  // slices write raw sums into fp32 slabs; a reduce launch applies the epilogue
+      p.out = slab; p.out_bf16 = 0;
       SplitKReduceArgs ra{};
       ra.slab = slab; ra.nsplit = a.ksplit; ra.slab_stride = a.slab_stride;
       ra.M = (long long)a.B * a.Ho * a.Wo; ra.N = a.Cout; ra.HW = a.Ho * a.Wo;
       ra.bias = a.bias; ra.film = a.film; ra.film_bs = a.film_bs;
-      ra.resid = a.resid; ra.resid_ld = a.resid_ld; ra.out = a.out;
+      ra.resid = a.resid; ra.resid_ld = a.resid_ld; ra.out = a.out; ra.act_bf16 = a.act_bf16;
       add_op(ex, DSX_OP_CONV_MFMA, d + fmt(" splitK%d", a.ksplit), flops, bytes,
              [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, p, st); });
       add_op(ex, DSX_OP_SPLITK_REDUCE, fmt("splitk_reduce x%d %d ch @%dx%d", a.ksplit, a.Cout, a.Ho, a.Wo), 0.0,
-             4.0 * (a.ksplit + 1) * (double)ra.M * ra.N,
+             (4.0 * a.ksplit + esz) * (double)ra.M * ra.N,
              [=](hipStream_t st) { return launch_splitk_reduce(ra, st); });
     } else {
       static const int ws_on = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
@@ -744,7 +757,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         w.ws_wg_per_n = std::max(unit, w.ws_wg_per_n / unit * unit);
         if (w.ws_wg_per_n > a.m_tiles) w.ws_wg_per_n = (a.m_tiles + unit - 1) / unit * unit;
       }
-      if (ws_on && stride == 1 && a.stage_mode == 0 && (a.Cout & 3) == 0 && conv_ws_lds_bytes(dtype, tile, ks, w) != 0) {
+      if (ws_on && stride == 1 && a.stage_mode == 0 && conv_ws_lds_bytes(dtype, tile, ks, w) != 0) {
         add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
                [=](hipStream_t st) { return launch_conv_ws(dtype, tile, ks, w, st); });
       } else {
@@ -778,10 +791,10 @@ static void plan_stats(dsx_exec* ex, const Tensor& t) {
   si.f32 = false;
   ex->launches++;
   if (ex->sizing) return;
-  const float* x = t.p; double* part = (double*)si.part;
-  const int B = ex->B, C = t.C;
-  add_op(ex, DSX_OP_GN_STATS, fmt("gn_stats C=%d @%dx%d", C, t.H, t.W), 0.0, 4.0 * B * HW * C,
-         [=](hipStream_t st) { return launch_chan_stats(x, B, HW, C, nchunk, part, st); });
+  const void* x = t.p; double* part = (double*)si.part;
+  const int B = ex->B, C = t.C, xbf = t.bf16 ? 1 : 0;
+  add_op(ex, DSX_OP_GN_STATS, fmt("gn_stats C=%d @%dx%d", C, t.H, t.W), 0.0, (xbf ? 2.0 : 4.0) * B * HW * C,
+         [=](hipStream_t st) { return launch_chan_stats(x, xbf, B, HW, C, nchunk, part, st); });
 }
 
 // GroupNorm over cat(t0, t1) -> device scale/shift [B][C]
@@ -847,21 +860,23 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   ex->launches += 3;
   if (!ex->sizing) {
     BgemmArgs g1{};
-    g1.A = qkv.p; g1.lda = 3 * C; g1.sA = (long long)L * 3 * C;
-    g1.Bm = qkv.p + C; g1.ldb = 3 * C; g1.sB = g1.sA; g1.b_kmajor = 0;
-    g1.Cm = S; g1.ldc = L; g1.sC = (long long)L * L;
+    const int abf = qkv.bf16 ? 1 : 0;
+    const double esz = abf ? 2.0 : 4.0;
+    g1.A = qkv.p; g1.lda = 3 * C; g1.sA = (long long)L * 3 * C; g1.a_bf16 = abf;
+    g1.Bm = qkv.at(C); g1.ldb = 3 * C; g1.sB = g1.sA; g1.b_kmajor = 0; g1.b_bf16 = abf;
+    g1.Cm = S; g1.ldc = L; g1.sC = (long long)L * L; g1.c_bf16 = 0;
     g1.M = L; g1.N = L; g1.K = C; g1.batch = B; g1.div = sqrtf((float)C);
     add_op(ex, DSX_OP_ATTN_GEMM, fmt("attn QK^T L=%d d=%d", L, C), 2.0 * B * L * (double)L * C,
-           4.0 * B * (2.0 * L * C + (double)L * L), [=](hipStream_t st) { return launch_bgemm(g1, st); });
+           B * (esz * 2.0 * L * C + 4.0 * (double)L * L), [=](hipStream_t st) { return launch_bgemm(g1, st); });
     add_op(ex, DSX_OP_SOFTMAX, fmt("softmax L=%d", L), 0.0, 8.0 * B * (double)L * L,
            [=](hipStream_t st) { return launch_softmax_rows(S, (long long)B * L, L, st); });
     BgemmArgs g2{};
-    g2.A = S; g2.lda = L; g2.sA = (long long)L * L;
-    g2.Bm = qkv.p + 2 * C; g2.ldb = 3 * C; g2.sB = (long long)L * 3 * C; g2.b_kmajor = 1;
-    g2.Cm = av.p; g2.ldc = C; g2.sC = (long long)L * C;
+    g2.A = S; g2.lda = L; g2.sA = (long long)L * L; g2.a_bf16 = 0;
+    g2.Bm = qkv.at(2 * (size_t)C); g2.ldb = 3 * C; g2.sB = (long long)L * 3 * C; g2.b_kmajor = 1; g2.b_bf16 = abf;
+    g2.Cm = av.p; g2.ldc = C; g2.sC = (long long)L * C; g2.c_bf16 = av.bf16 ? 1 : 0;
     g2.M = L; g2.N = C; g2.K = L; g2.batch = B; g2.div = 1.0f;
     add_op(ex, DSX_OP_ATTN_GEMM, fmt("attn PV L=%d d=%d", L, C), 2.0 * B * L * (double)L * C,
-           4.0 * B * (2.0 * L * C + (double)L * L), [=](hipStream_t st) { return launch_bgemm(g2, st); });
+           B * (esz * 2.0 * L * C + 4.0 * (double)L * L), [=](hipStream_t st) { return launch_bgemm(g2, st); });
   }
   Tensor o2 = new_tensor(ex, C, H, W);
   ConvSpec co{};
@@ -886,6 +901,8 @@ static int build_plan(dsx_exec* ex) {
   ex->in_cond = Tensor();
   if (ex->cond_c) ex->in_cond = new_tensor(ex, ex->cond_c, ex->H, ex->W);
   ex->in_x = new_tensor(ex, ex->x_c, ex->H, ex->W);
+  ex->x_state = ex->in_x.bf16 ? (float*)ws_alloc(ex, (size_t)B * ex->H * ex->W * ex->x_c * sizeof(float))
+                              : (float*)ex->in_x.p;
   std::vector<Tensor> feats;
   Tensor x;
   int rc;
@@ -926,7 +943,7 @@ static int build_plan(dsx_exec* ex) {
     } else {
       float *s, *h;
       plan_gn(ex, md.gn1, x, nullptr, &s, &h);
-      Tensor o = new_tensor(ex, md.cout, x.H, x.W);
+      Tensor o = new_tensor(ex, md.cout, x.H, x.W, /*f32=*/true);   // the network's output feeds the fp32 sampler update
       ConvSpec c{};
       c.w = &md.conv; c.x0 = x; c.gn_scale = s; c.gn_shift = h; c.has_gn = true; c.swish = true; c.out = o;
       if ((rc = plan_conv(ex, c))) return rc;
@@ -934,6 +951,7 @@ static int build_plan(dsx_exec* ex) {
     }
   }
   ex->out = x;
+  if (ex->out.bf16) return fail(DSX_ERR_STATE, "internal error: the network output must be an fp32 tensor");
   if (ex->overflow)
     return fail(DSX_ERR_STATE, "internal error: the planning pass needs more workspace than the sizing pass reserved");
   return DSX_OK;
@@ -1062,7 +1080,7 @@ extern "C" int dsx_unet_forward(dsx_exec* ex, const float* x, const float* time,
   int rc = load_inputs(ex, ex->cond_c ? x : nullptr, x, m->cfg.in_channel, ex->cond_c, st);
   if (rc) return rc;
   if ((rc = run_unet(ex, false, n_time, st))) return rc;
-  HIP_TRY(launch_nhwc_to_nchw(ex->out.p, y, ex->B, ex->out.C, ex->H, ex->W, st));
+  HIP_TRY(launch_nhwc_to_nchw((const float*)ex->out.p, y, ex->B, ex->out.C, ex->H, ex->W, st));
   return DSX_OK;
 }
 
@@ -1072,9 +1090,13 @@ static int load_inputs(dsx_exec* ex, const float* cond_nchw, const float* x_nchw
   if (ex->cond_c) {
     if (!cond_nchw) return fail(DSX_ERR_INVALID, "this executor was created with cond_channels > 0");
     const int ctot = (cond_nchw == x_nchw) ? x_total_c : ex->cond_c;
-    HIP_TRY(dsx::launch_nchw_slice_to_nhwc(cond_nchw, ex->in_cond.p, ex->B, ex->cond_c, ctot, 0, HW, st));
+    HIP_TRY(dsx::launch_nchw_slice_to_nhwc(cond_nchw, ex->in_cond.p, ex->in_cond.bf16 ? 1 : 0, ex->B, ex->cond_c, ctot,
+                                           0, HW, st));
   }
-  HIP_TRY(dsx::launch_nchw_slice_to_nhwc(x_nchw, ex->in_x.p, ex->B, ex->x_c, x_total_c, x_c_off, HW, st));
+  HIP_TRY(dsx::launch_nchw_slice_to_nhwc(x_nchw, ex->in_x.p, ex->in_x.bf16 ? 1 : 0, ex->B, ex->x_c, x_total_c, x_c_off,
+                                         HW, st));
+  if (ex->in_x.bf16)   // the sampler state itself stays fp32
+    HIP_TRY(dsx::launch_nchw_slice_to_nhwc(x_nchw, ex->x_state, 0, ex->B, ex->x_c, x_total_c, x_c_off, HW, st));
   return DSX_OK;
 }
 
@@ -1104,7 +1126,8 @@ static int enqueue_step(dsx_exec* ex, const dsx_step_table* tab, const float* no
   int rc = run_unet(ex, true, 1, st);
   if (rc) return rc;
   UpdateArgs u{};
-  u.x = ex->in_x.p; u.net = ex->out.p; u.noise = noise; u.seed = seed;
+  u.x = ex->x_state; u.x_act = ex->in_x.bf16 ? ex->in_x.p : nullptr;
+  u.net = (const float*)ex->out.p; u.noise = noise; u.seed = seed;
   u.tab = ex->table; u.n_steps = ex->table_cap; u.step_ctr = ex->step_ctr;
   u.predict_eps = tab->predict_eps; u.clip = tab->clip;
   u.B = ex->B; u.C = ex->x_c; u.H = ex->H; u.W = ex->W;
@@ -1171,12 +1194,12 @@ extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const fl
     if (graph_ok) HIP_TRY(hipGraphLaunch(ex->graph_exec, st));
     else if ((rc = enqueue_step(ex, tab, noise, seed, st))) return rc;
     while (snap_i < n_snap && snap_steps[snap_i] == s) {
-      HIP_TRY(launch_nhwc_to_nchw(ex->in_x.p, snaps + (size_t)snap_i * snap_elems, ex->B, ex->x_c, ex->H,
+      HIP_TRY(launch_nhwc_to_nchw(ex->x_state, snaps + (size_t)snap_i * snap_elems, ex->B, ex->x_c, ex->H,
                                   ex->W, st));
       ++snap_i;
     }
   }
-  HIP_TRY(launch_nhwc_to_nchw(ex->in_x.p, x, ex->B, ex->x_c, ex->H, ex->W, st));
+  HIP_TRY(launch_nhwc_to_nchw(ex->x_state, x, ex->B, ex->x_c, ex->H, ex->W, st));
   return DSX_OK;
 }
 
@@ -1213,11 +1236,12 @@ extern "C" int dsx_time_predictor_forward(dsx_exec* ex, const float* x, float* t
   if ((rc = run_unet(ex, false, 1, st))) return rc;
   NaiveConvArgs na{};
   na.c.src0 = ex->in_x.p; na.c.C0 = ex->x_c; na.c.C1 = 0;
+  na.c.act_bf16 = ex->in_x.bf16 ? 1 : 0; na.c.out_bf16 = 0;
   na.c.B = ex->B; na.c.Hs = ex->H; na.c.Ws = ex->W; na.c.Ho = ex->H; na.c.Wo = ex->W;
   na.c.bias = ex->tp_b; na.c.out = ex->tp_mask; na.c.out_ld = 1; na.c.Cout = 1;
   na.w = ex->tp_w; na.ks = 7; na.stride = 1; na.sigmoid_out = 1;
   HIP_TRY(launch_conv_naive(na, st));
-  HIP_TRY(launch_masked_mean(ex->out.p, ex->tp_mask, ex->B, (long long)ex->H * ex->W, t_out, st));
+  HIP_TRY(launch_masked_mean((const float*)ex->out.p, ex->tp_mask, ex->B, (long long)ex->H * ex->W, t_out, st));
   return DSX_OK;
 }
 
