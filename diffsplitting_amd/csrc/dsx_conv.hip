@@ -35,8 +35,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 
+// x * sigmoid(x).  v_exp + v_rcp (1 ulp each) instead of an IEEE division sequence (10 more VALU
+// instructions per element on the loaders' critical path); far inside the 1e-3 parity budget.
 __device__ __forceinline__ float swish_f(float v) {
-  return __fdividef(v, 1.0f + __expf(-v));
+  return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
 // sum over the 16 lanes of a DPP row; every lane of the row ends up with the total
@@ -685,63 +687,55 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   const int ntile = (a.m_tiles - p0 + wpn - 1) / wpn;
   const int total = ntile * G;                  // (tile, group) items, in order
 
-  auto tile_coords = [&](int ti, int& oy0, int& ox0, int& b0) {
-    const int mt = p0 + ti * wpn;
-    const int txi = mt % a.tiles_x;
-    const int tyi = (mt / a.tiles_x) % a.tiles_y;
-    const int bg = mt / (a.tiles_x * a.tiles_y);
-    oy0 = tyi << a.th_log2; ox0 = txi << a.tw_log2; b0 = bg << a.tb_log2;
-  };
-
   if (loader) {
     // ======================================================================= LOADER WAVES
+    // Per-thread, tile-invariant description of its NIT units: LDS image offset, source pixel offset
+    // relative to the tile's origin pixel, and which patch borders the unit lies on.  Per tile only the
+    // origin offset and four "tile touches the image border" flags change (no divisions, no per-unit
+    // bounds arithmetic): zero padding is exactly the border units of border tiles.
+    struct TilePos { int tx, ty, b; };
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int adv_x = wpn % a.tiles_x, adv_y = (wpn / a.tiles_x) % a.tiles_y, adv_b = wpn / per_img;
+    auto tile_advance = [&](TilePos& t) {
+      t.tx += adv_x;
+      if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; t.ty += 1; }
+      t.ty += adv_y;
+      if (t.ty >= a.tiles_y) { t.ty -= a.tiles_y; t.b += 1; }
+      t.b += adv_b;
+    };
+    auto tile_flags = [&](const TilePos& t) -> int {   // bit0 top, bit1 bottom, bit2 left, bit3 right
+      return (PAD == 0) ? 0
+                        : ((t.ty == 0 ? 1 : 0) | (t.ty == a.tiles_y - 1 ? 2 : 0) | (t.tx == 0 ? 4 : 0) |
+                           (t.tx == a.tiles_x - 1 ? 8 : 0));
+    };
+    // source pixel index of the patch origin's *output* pixel (oy0, ox0); `rel` is added to it
+    auto tile_base = [&](const TilePos& t) -> int {
+      const int oy0 = t.ty << a.th_log2, ox0 = t.tx << a.tw_log2;   // even whenever a.up (TW, TH >= 2)
+      return (t.b * a.Hs + (a.up ? oy0 >> 1 : oy0)) * a.Ws + (a.up ? ox0 >> 1 : ox0);
+    };
     const int nunits = PP << UPG_LOG2;
     const int cvg = ltid & (UPG - 1);
-    int loff[NIT];            // LDS image offset of each unit (tile-invariant), -1: no such unit
-    int dpy_, dpx_;
-    int tb0, py0, px0;        // (tb,py,px) of this thread's first unit
+    int loff[NIT];            // LDS image offset of each unit, -1: no such unit
+    int rel[NIT];             // source pixel offset relative to tile_base
+    int edge[NIT];            // border bits of the unit's patch pixel
     {
       constexpr int PSTEP = LT >> UPG_LOG2;
       const int pix0 = ltid >> UPG_LOG2;
-      tb0 = pix0 / PPI;
-      const int rem = pix0 - tb0 * PPI;
-      py0 = rem / PW;
-      px0 = rem - py0 * PW;
-      dpy_ = PSTEP / PW; dpx_ = PSTEP - dpy_ * PW;
-      int tb = tb0, py = py0, px = px0;
+      int py = pix0 / PW;
+      int px = pix0 - py * PW;
+      const int dpy = PSTEP / PW, dpx = PSTEP - dpy * PW;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        loff[it] = (ltid + it * LT < nunits) ? (tb * PH + py) * RB + px * PIXB + cvg * UB : -1;
-        px += dpx_; py += dpy_;
+        const bool have = ltid + it * LT < nunits;
+        loff[it] = have ? py * RB + px * PIXB + cvg * UB : -1;
+        const int ry = py - PAD, rx = px - PAD;   // relative to the tile's first output pixel (input grid)
+        // nearest x2 upsample: source = floor(input / 2); the origin is even, so floor((o + r) / 2) = o/2 + (r >> 1)
+        rel[it] = a.up ? (ry >> 1) * a.Ws + (rx >> 1) : ry * a.Ws + rx;
+        edge[it] = (PAD == 0) ? 0 : ((py == 0 ? 1 : 0) | (py == PH - 1 ? 2 : 0) | (px == 0 ? 4 : 0) | (px == PW - 1 ? 8 : 0));
+        px += dpx; py += dpy;
         if (px >= PW) { px -= PW; py += 1; }
-        while (py >= PH) { py -= PH; tb += 1; }
       }
     }
-    // source pixel index per unit for tile `ti` (-1: zero padding / outside the batch / no unit)
-    auto make_plan = [&](int ti, int* soff, int& b0_out) {
-      int oy0, ox0, b0;
-      tile_coords(ti, oy0, ox0, b0);
-      b0_out = b0;
-      const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-      int tb = tb0, py = py0, px = px0;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        int so = -1;
-        const int b = b0 + tb;
-        if (loff[it] >= 0) {
-          const int iy = iy0 + py, ix = ix0 + px;
-          if (b < a.B && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) {
-            const int sy = a.up ? (iy >> 1) : iy;
-            const int sx = a.up ? (ix >> 1) : ix;
-            so = (b * a.Hs + sy) * a.Ws + sx;
-          }
-        }
-        soff[it] = so;
-        px += dpx_; py += dpy_;
-        if (px >= PW) { px -= PW; py += 1; }
-        while (py >= PH) { py -= PH; tb += 1; }
-      }
-    };
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.src0, 0, (int)min((long long)a.B * a.Hs * a.Ws * a.C0 * ES, 0x7fffffffLL), 0x00020000);
@@ -749,14 +743,11 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         (void*)(a.src1 ? a.src1 : a.src0), 0,
         a.src1 ? (int)min((long long)a.B * a.Hs * a.Ws * a.C1 * ES, 0x7fffffffLL) : 0, 0x00020000);
 
-    int soffI[NIT], soffC[NIT];
-    int b0I = 0, b0C = 0;
+    TilePos posI{p0 % a.tiles_x, (p0 / a.tiles_x) % a.tiles_y, p0 / per_img};   // tile being issued
+    TilePos posC = posI;                                                         // tile being consumed
+    int baseI = tile_base(posI), flagsI = tile_flags(posI), flagsC = flagsI;
     int tiI = 0, gI = 0;      // next item to issue
     int tiC = 0, gC = 0;      // next item to consume
-    make_plan(0, soffI, b0I);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) soffC[it] = soffI[it];
-    b0C = b0I;
 
     // DMA the raw patch of item (tiI, gI) into ring slot `slot`; every wave issues exactly NIT instructions
     auto issue = [&](int slot) {
@@ -767,12 +758,17 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       unsigned char* dst = raw_base + slot * RAWB + wave * 1024;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const unsigned vo = soffI[it] >= 0 ? (unsigned)soffI[it] * (unsigned)(cs * ES) + coff : 0x80000000u;
+        const bool ok = loff[it] >= 0 && (edge[it] & flagsI) == 0;
+        const unsigned vo = ok ? (unsigned)(baseI + rel[it]) * (unsigned)(cs * ES) + coff : 0x80000000u;
         auto ldst = (__attribute__((address_space(3))) void*)(dst + it * (LT * 16));
         if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, ldst, 16, vo, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, ldst, 16, vo, 0, 0, 0);
       }
-      if (++gI == G) { gI = 0; ++tiI; if (tiI < ntile) make_plan(tiI, soffI, b0I); }
+      if (++gI == G) {
+        gI = 0; ++tiI;
+        tile_advance(posI);
+        baseI = tile_base(posI); flagsI = tile_flags(posI);
+      }
     };
     // raw slot -> GroupNorm affine + Swish -> MFMA image `buf` for item (tiC, gC)
     auto consume = [&](int slot, int buf) {
@@ -818,7 +814,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         if (loff[it] >= 0) {
           float v[CPU];
           Unit<DT>::unpack(__builtin_bit_cast(uint4, rv[it]), v);
-          if (soffC[it] >= 0 && c < C) {
+          if ((edge[it] & flagsC) == 0 && c < C) {   // padding pixels stay exactly 0 (padded AFTER the activation)
             if (has_gn) {
 #pragma unroll
               for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
@@ -834,7 +830,11 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
           lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, Unit<DT>::pack(v)));
         }
       }
-      if (++gC == G) { gC = 0; ++tiC; if (tiC < ntile) make_plan(tiC, soffC, b0C); }
+      if (++gC == G) {
+        gC = 0; ++tiC;
+        tile_advance(posC);
+        flagsC = tile_flags(posC);
+      }
     };
     // wait until item w's DMAs have landed: only the k = min(P, total-1-w) younger groups may stay in flight
     auto wait_item = [&](int w) {
@@ -1204,14 +1204,22 @@ static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activati
   return bm == 64 ? 4 : (ks == 1 ? 2 : 3);
 }
 static constexpr int kWsLoaderWaves = 4;
+// patch pixels the WS loaders are sized for: one image per tile, square-ish tiles (16x8 / 8x16 -> 18x10,
+// 8x8 -> 10x10, 16x4 -> 18x6); other shapes fall back to k_conv_mfma
+static constexpr int ws_max_px(int tile, int ks) {
+  const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
+  return ks == 1 ? bm : (bm == 128 ? 180 : 108);
+}
 static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units per loader thread per group
   const int upg = 4 * conv_cpg(ks);
   (void)dtype;
-  return (max_px(tile, ks, 1) * upg + kWsLoaderWaves * 64 - 1) / (kWsLoaderWaves * 64);
+  return (ws_max_px(tile, ks) * upg + kWsLoaderWaves * 64 - 1) / (kWsLoaderWaves * 64);
 }
 size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   if (!ws_tile_ok(tile) || !(ks == 1 || ks == 3)) return 0;
   if (conv_lds_bytes(dtype, tile, ks, 1, a) == 0) return 0;
+  if (patch_pixels(ks, 1, a) > ws_max_px(tile, ks)) return 0;
+  if (a.up && (a.tw_log2 == 0 || a.th_log2 == 0)) return 0;   // the loaders assume an even tile origin when upsampling
   const int ph = ((1 << a.th_log2) - 1) + ks;
   const size_t bufb = (size_t)(ph << a.tb_log2) * a.lds_row;
   const size_t rawb = (size_t)ws_nit(dtype, tile, ks) * (kWsLoaderWaves * 64 * 16);
