@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
 
-  constexpr bool STATS = MB <= 2;
+  constexpr bool STATS = MB <= 4;   // 256 VGPRs per wave here: the statistics fit in every tile
   const bool do_stats = STATS && a.stat_part != nullptr;
   const int nbase = blk * 32 + 16 * lh;         // this lane's 16 consecutive channels
 
@@ -1107,6 +1107,7 @@ ConvTileInfo conv_tile_info(int tile) {
 
 int conv_tile_wm(int tile) { return kTiles[tile].WM; }
 bool conv_tile_fuses_stats(int tile) { return kTiles[tile].MB <= 2; }
+bool conv_ws_fuses_stats(int tile) { return kTiles[tile].MB <= 4; }
 
 static constexpr int conv_cpg(int ks) { return ks == 1 ? 2 : 1; }
 
@@ -1197,7 +1198,7 @@ hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& 
 
 // ---- warp-specialised variant: per (dtype, tile, ks) constants
 static constexpr bool ws_tile_ok(int tile) {
-  return tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;   // MB <= 2: epilogue operands fit in registers
+  return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;
 }
 static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activations in flight beyond the current one
   const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;

@@ -58,7 +58,8 @@ enum ConvTile { TILE_256x128 = 0, TILE_128x128, TILE_64x128, TILE_256x64, TILE_1
 struct ConvTileInfo { int BM, BN; };
 ConvTileInfo conv_tile_info(int tile);
 int conv_tile_wm(int tile);   // waves along M (one statistics row per (tile, wm))
-bool conv_tile_fuses_stats(int tile);
+bool conv_tile_fuses_stats(int tile);   // k_conv_mfma
+bool conv_ws_fuses_stats(int tile);     // k_conv_ws
 // input-channel chunks are staged in groups of this many (weights are packed/padded to it)
 int conv_chunk_multiple(int ks);
 int conv_lds_row(int ks, int stride, int tw_log2);
@@ -144,6 +145,7 @@ struct SplitKReduceArgs {
   const void* resid; int resid_ld;
   void* out;
   int act_bf16;                          // resid and out hold bf16
+  float* stat_part;                      // nullptr, or GroupNorm partials [B][HW/16][N][2] of `out` (N % 64 == 0, HW % 16 == 0)
 };
 hipError_t launch_splitk_reduce(const SplitKReduceArgs& a, hipStream_t st);
 hipError_t launch_softmax_rows(float* S, long long rows, int L, hipStream_t st);

@@ -345,7 +345,55 @@ __global__ void k_splitk_reduce(const SplitKReduceArgs a) {
     store1_act(a.out, (size_t)i, v, a.act_bf16);
   }
 }
+// same, plus the GroupNorm statistics of the tensor it writes: one workgroup per (image, 16-pixel chunk,
+// 64 channels), 4 pixel lanes x 4 pixels per channel, fixed reduction order.
+// stat_part[b][chunk][n][{sum, sumsq}] with HW/16 chunks per image.
+__global__ __launch_bounds__(256) void k_splitk_reduce_stats(const SplitKReduceArgs a) {
+  __shared__ float red[2][4][64];
+  const int b = blockIdx.x, ch = blockIdx.z, n = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const float* __restrict__ slab = a.slab;
+  const float bi = a.bias ? a.bias[n] : 0.f;
+  const float fl = a.film ? a.film[(size_t)b * a.film_bs + n] : 0.f;
+  float v[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+  size_t idx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long m = (long long)b * a.HW + ch * 16 + pl * 4 + k;
+    idx[k] = (size_t)m * a.N + n;
+    if (a.resid) rs[k] = load1_act(a.resid, (size_t)m * a.resid_ld + n, a.act_bf16);
+  }
+  for (int s = 0; s < a.nsplit; ++s) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += slab[(size_t)s * a.slab_stride + idx[k]];
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float x = v[k];
+    if (a.bias) x += bi;
+    if (a.film) x += fl;
+    if (a.resid) x += rs[k];
+    store1_act(a.out, idx[k], x, a.act_bf16);
+    s1 += x; s2 += x * x;
+  }
+  red[0][pl][threadIdx.x & 63] = s1;
+  red[1][pl][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x;
+    const float t1 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    const float t2 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    float* pp = a.stat_part + (((size_t)b * gridDim.z + ch) * a.N + n) * 2;
+    pp[0] = t1; pp[1] = t2;
+  }
+}
 hipError_t launch_splitk_reduce(const SplitKReduceArgs& a, hipStream_t st) {
+  if (a.stat_part) {
+    if (a.N % 64 != 0 || a.M % a.HW != 0 || a.HW % 16 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_splitk_reduce_stats, dim3((unsigned)(a.M / a.HW), (unsigned)(a.N / 64), (unsigned)(a.HW / 16)),
+                       dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   long long g = (a.M * a.N + 255) / 256;
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)g), dim3(256), 0, st, a);

@@ -614,7 +614,11 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   // tile (least re-staging of the activations per output channel) that still gives >= ws_min work items.
   static const int ws_on = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
   static const int ws_min = getenv("DSX_WS_MIN_GRID") ? atoi(getenv("DSX_WS_MIN_GRID")) : 224;
-  static const std::vector<int> ws_wide = tile_order("DSX_TILES_WS_WIDE", {TILE_64x128, TILE_128x128});
+  // 3x3: the 64-pixel tile (two MFMAs per weight fragment keeps LDS and L1 in balance); 1x1: the 128-pixel tile
+  // (no tap reuse of the image, so the longer MFMA run per barrier wins)
+  static const std::vector<int> ws_wide3 = tile_order("DSX_TILES_WS_WIDE", {TILE_64x128, TILE_128x128});
+  static const std::vector<int> ws_wide1 = tile_order("DSX_TILES_WS_WIDE_1X1", {TILE_128x128, TILE_64x128});
+  const std::vector<int>& ws_wide = ks == 1 ? ws_wide1 : ws_wide3;
   static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_128x64, TILE_64x64});
   if (ws_on && stride == 1 && a.stage_mode == 0) {
     for (int tile : (is_wide ? ws_wide : ws_narrow)) {
@@ -695,7 +699,11 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
   ex->launches++;
   static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
-  if (fuse_stats && s.want_stats && mfma_ok && conv_tile_fuses_stats(tile) && a.ksplit == 1 && a.tb_log2 == 0 &&
+  static const int ws_enabled = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
+  const bool use_ws = mfma_ok && ws_enabled && stride == 1 && a.stage_mode == 0 && a.ksplit == 1 &&
+                      conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
+  if (fuse_stats && s.want_stats && mfma_ok && (use_ws ? conv_ws_fuses_stats(tile) : conv_tile_fuses_stats(tile)) &&
+      a.ksplit == 1 && a.tb_log2 == 0 &&
       (a.Cout & 15) == 0 &&
       a.out_ld == a.Cout && (a.resid_ld & 7) == 0) {
     StatInfo& si = ex->stats[s.out.id];
@@ -719,9 +727,18 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
     ex->conv_ordinal++;
   }
   float* slab = nullptr;
+  float* reduce_stats = nullptr;
   if (mfma_ok && a.ksplit > 1) {
     slab = (float*)ws_alloc(ex, (size_t)a.ksplit * a.slab_stride * sizeof(float));
     ex->launches++;
+    if (fuse_stats && s.want_stats && a.Cout % 64 == 0 && a.out_ld == a.Cout && (a.Ho * a.Wo) % 16 == 0) {
+      StatInfo& si = ex->stats[s.out.id];   // statistics in the reduce launch
+      si.nchunk = a.Ho * a.Wo / 16;
+      si.part = ws_alloc(ex, (size_t)a.B * si.nchunk * a.Cout * 2 * sizeof(float));
+      si.planned = true;
+      si.f32 = true;
+      reduce_stats = (float*)si.part;
+    }
   }
   if (ex->sizing) return DSX_OK;
   const double npix = (double)a.B * a.Ho * a.Wo;
@@ -743,13 +760,13 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       ra.M = (long long)a.B * a.Ho * a.Wo; ra.N = a.Cout; ra.HW = a.Ho * a.Wo;
       ra.bias = a.bias; ra.film = a.film; ra.film_bs = a.film_bs;
       ra.resid = a.resid; ra.resid_ld = a.resid_ld; ra.out = a.out; ra.act_bf16 = a.act_bf16;
+      ra.stat_part = reduce_stats;
       add_op(ex, DSX_OP_CONV_MFMA, d + fmt(" splitK%d", a.ksplit), flops, bytes,
              [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, p, st); });
       add_op(ex, DSX_OP_SPLITK_REDUCE, fmt("splitk_reduce x%d %d ch @%dx%d", a.ksplit, a.Cout, a.Ho, a.Wo), 0.0,
              (4.0 * a.ksplit + esz) * (double)ra.M * ra.N,
              [=](hipStream_t st) { return launch_splitk_reduce(ra, st); });
     } else {
-      static const int ws_on = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
       ConvArgs w = a;
       w.ws_wg_per_n = std::min(a.m_tiles, std::max(1, 256 / std::max(1, a.n_tiles)));
       if (a.n_tiles <= 8 && 8 % a.n_tiles == 0) {   // whole XCD groups per N tile (see k_conv_ws)
@@ -757,7 +774,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         w.ws_wg_per_n = std::max(unit, w.ws_wg_per_n / unit * unit);
         if (w.ws_wg_per_n > a.m_tiles) w.ws_wg_per_n = (a.m_tiles + unit - 1) / unit * unit;
       }
-      if (ws_on && stride == 1 && a.stage_mode == 0 && conv_ws_lds_bytes(dtype, tile, ks, w) != 0) {
+      if (use_ws) {
         add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
                [=](hipStream_t st) { return launch_conv_ws(dtype, tile, ks, w, st); });
       } else {
