@@ -24,6 +24,7 @@
 //   epilogue     : accumulator rows are pixels, columns are channels -> each
 //                  store instruction writes 2 x 128 B contiguous NHWC segments.
 #include "dsx_kernels.h"
+#include <algorithm>
 
 #ifndef DSX_RING_DEPTH
 #define DSX_RING_DEPTH 6  // weight-fragment prefetch ring depth for 3x3 (divides 18)
@@ -921,11 +922,18 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     if (t.ty >= a.tiles_y) { t.ty -= a.tiles_y; t.b += 1; }
     t.b += adv_b;
   };
-  // output pixel of this lane's row in M block mb of tile t
-  auto out_pixel = [&](const TilePos& t, int mb) -> size_t {
+  // element offsets (32-bit; host: tensors < 2^31 elements) of this lane's output rows: a tile-invariant
+  // per-row part, precomputed, plus a wave-uniform per-tile part -> no per-tile vector multiplies
+  int orow[MB], rrow[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
     const int m = (wm * MB + mb) * 32 + li;
-    const int tx = m & (TW - 1), ty = m >> a.tw_log2;
-    return ((size_t)t.b * a.Ho + ((t.ty << a.th_log2) + ty)) * a.Wo + ((t.tx << a.tw_log2) + tx);
+    const int pix = (m >> a.tw_log2) * a.Wo + (m & (TW - 1));
+    orow[mb] = pix * a.out_ld + nbase;
+    rrow[mb] = pix * a.resid_ld + nbase;
+  }
+  auto tile_pixel0 = [&](const TilePos& t) -> int {   // first output pixel of tile t (uniform)
+    return (t.b * a.Ho + (t.ty << a.th_log2)) * a.Wo + (t.tx << a.tw_log2);
   };
   TilePos cur{p0 % a.tiles_x, (p0 / a.tiles_x) % a.tiles_y, p0 / per_img};   // tile ti (being multiplied)
   TilePos nxt = cur;       // tile ti + 1
@@ -968,9 +976,10 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       for (int j = 0; j < 4; ++j) filmv[j] = *(const float4*)(a.film + (size_t)t.b * a.film_bs + nbase + 4 * j);
     }
     if (a.resid) {
+      const int r0 = tile_pixel0(t) * a.resid_ld;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const DT* rp = (const DT*)a.resid + out_pixel(t, mb) * a.resid_ld + nbase;
+        const DT* rp = (const DT*)a.resid + (r0 + rrow[mb]);
 #pragma unroll
         for (int q = 0; q < NR; ++q) residv[mb][q] = *(const uint4*)(rp + CPU * q);
       }
@@ -1056,13 +1065,14 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    const int o0 = tile_pixel0(done) * a.out_ld;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       {
         float x[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = acc[mb][r];
-        store16<true>(a.out, out_pixel(done, mb) * a.out_ld + nbase, x, IS_BF16, 16);   // host: out is in the storage type
+        store16<true>(a.out, (size_t)(o0 + orow[mb]), x, IS_BF16, 16);   // host: out is in the storage type
       }
       if constexpr (STATS) {
 #pragma unroll
@@ -1228,6 +1238,7 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   const size_t total = 2 * bufb + 2 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb;
   if (a.tb_log2 != 0 || a.kchunks / conv_cpg(ks) < 2) return 0;   // one image per tile, >= 2 channel groups
   // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
+  if ((long long)a.B * a.Ho * a.Wo * std::max(a.out_ld, a.resid_ld) >= (1LL << 31)) return 0;   // 32-bit element offsets
   const int al = dtype == 1 ? 7 : 3;   // 16-byte rows in elements of the storage type
   if (a.Cout % (32 * kTiles[tile].WN) != 0 || (a.out_ld & al) != 0 || (a.resid_ld & al) != 0 || a.C0 + a.C1 > 1024) return 0;
   if (dtype == 1 && !(a.act_bf16 && a.out_bf16)) return 0;   // this kernel reads and writes the storage type only

@@ -71,6 +71,7 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a);
 hipError_t launch_conv_ws(int dtype, int tile, int ks, const ConvArgs& a, hipStream_t st);
 // one-time function attributes (dynamic LDS limit); call outside any stream capture
 hipError_t conv_init();
+hipError_t ops_init();
 
 // Plain direct convolution (one thread per output element), any odd KS, stride 1,
 // weights [Cout][KS][KS][Cin] fp32.  Used for the 7x7 ForegroundMask conv and as

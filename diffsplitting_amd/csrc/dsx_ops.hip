@@ -324,9 +324,133 @@ __global__ __launch_bounds__(256) void k_bgemm(const BgemmArgs a) {
   }
 }
 
+// bf16 build: the same batched GEMM on v_mfma_f32_32x32x16_bf16.  Operands are bf16 in HBM (q, k, v) or
+// fp32 (the softmax output) and are rounded to bf16 (RNE) on the way into LDS; accumulation is fp32.
+// K chunks of 64 through LDS rows of 144 bytes (conflict-free ds_read_b128 of a 32-row fragment), the next
+// chunk's global loads in flight during the current chunk's MFMAs.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+  const __bf16 l = (__bf16)lo, h = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+}
+template <int KC>
+__global__ __launch_bounds__(256) void k_bgemm_bf16(const BgemmArgs a) {
+  // KC = K elements staged per barrier: with KC = 256 the whole K extent of the attention GEMMs is two
+  // load phases (every load of a phase in flight at once) instead of one exposed latency per 64 elements.
+  constexpr int LDB = (KC + 8) * 2;            // bytes per LDS row; (KC + 8) / 2 mod 32 == 4 -> conflict-free b128 reads
+  constexpr int NV = KC / 32;                  // 16-byte pieces per thread per operand
+  extern __shared__ __attribute__((aligned(16))) unsigned char bg_lds[];
+  unsigned char* As = bg_lds;
+  unsigned char* Bs = bg_lds + 64 * LDB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_n = (a.N + 63) / 64;
+  const int tiles_m = (a.M + 63) / 64;
+  const int bt = blockIdx.x / (tiles_m * tiles_n);
+  const int t = blockIdx.x % (tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
+  const size_t A0 = (size_t)bt * a.sA, B0 = (size_t)bt * a.sB, C0 = (size_t)bt * a.sC;
+  // 8 consecutive elements -> 8 bf16 (packed); sources are bf16 (copied) or fp32 (rounded RNE)
+  auto load8p = [&](const void* base, int bf16, size_t i, bool al, int nvalid) -> uint4 {
+    if (al && nvalid >= 8) {
+      if (bf16) return *(const uint4*)((const unsigned short*)base + i);
+      const float4 u = *(const float4*)((const float*)base + i), w = *(const float4*)((const float*)base + i + 4);
+      return make_uint4(pack2_bf16(u.x, u.y), pack2_bf16(u.z, u.w), pack2_bf16(w.x, w.y), pack2_bf16(w.z, w.w));
+    }
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = j < nvalid ? load1_act(base, i + j, bf16) : 0.f;
+    return make_uint4(pack2_bf16(e[0], e[1]), pack2_bf16(e[2], e[3]), pack2_bf16(e[4], e[5]), pack2_bf16(e[6], e[7]));
+  };
+  // Global reads are 8 threads x 16 bytes = one 128-byte line per row per instruction (rows of the tile are
+  // contiguous in memory: M for A, N for an n-major B, K for a k-major B).
+  const int tr = tid >> 3, tc = (tid & 7) * 8;   // row inside a 32-row pass, first of 8 elements
+  // 64 rows x KC columns, piece q = (row half, 64-column block)
+  auto load_rows = [&](const void* base, int bf16, size_t off0, int ld, int row0, int rows, int col0, int cols,
+                       uint4 (&v)[NV]) {
+    const bool al = ((ld | off0 | (size_t)col0) & 7) == 0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int r = row0 + (q & 1) * 32 + tr, c = col0 + (q >> 1) * 64 + tc;
+      v[q] = r < rows ? load8p(base, bf16, off0 + (size_t)r * ld + c, al, cols - c) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_rows = [&](unsigned char* S, const uint4 (&v)[NV]) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      *(uint4*)(S + ((q & 1) * 32 + tr) * LDB + ((q >> 1) * 64 + tc) * 2) = v[q];
+  };
+  // k-major B (V[k][n]): KC k-rows x 64 n, piece q = 32-row pass; written transposed, LDS[n][k]
+  auto load_kmajor = [&](int k0, uint4 (&v)[NV]) {
+    const bool al = ((a.ldb | B0 | (size_t)n0) & 7) == 0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int k = k0 + q * 32 + tr;
+      v[q] = k < a.K ? load8p(a.Bm, a.b_bf16, B0 + (size_t)k * a.ldb + n0 + tc, al, a.N - (n0 + tc)) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_kmajor = [&](const uint4 (&v)[NV]) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned short hv = (unsigned short)(j & 1 ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu);
+        *(unsigned short*)(Bs + (tc + j) * LDB + (q * 32 + tr) * 2) = hv;
+      }
+    }
+  };
+  static_assert(NV == KC / 32, "pieces per thread");
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  uint4 ra[NV], rb[NV];
+  load_rows(a.A, a.a_bf16, A0, a.lda, m0, a.M, 0, a.K, ra);
+  if (!a.b_kmajor) load_rows(a.Bm, a.b_bf16, B0, a.ldb, n0, a.N, 0, a.K, rb); else load_kmajor(0, rb);
+  for (int k0 = 0; k0 < a.K; k0 += KC) {
+    store_rows(As, ra);
+    if (!a.b_kmajor) store_rows(Bs, rb); else store_kmajor(rb);
+    __syncthreads();
+    if (k0 + KC < a.K) {
+      load_rows(a.A, a.a_bf16, A0, a.lda, m0, a.M, k0 + KC, a.K, ra);
+      if (!a.b_kmajor) load_rows(a.Bm, a.b_bf16, B0, a.ldb, n0, a.N, k0 + KC, a.K, rb); else load_kmajor(k0 + KC, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < KC / 16; ++s) {
+      const bf16x8_t av = *(const bf16x8_t*)(As + (wm * 32 + li) * LDB + (s * 16 + lh * 8) * 2);
+      const bf16x8_t bv = *(const bf16x8_t*)(Bs + (wn * 32 + li) * LDB + (s * 16 + lh * 8) * 2);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + li;
+  if (n < a.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < a.M) store1_act(a.Cm, C0 + (size_t)m * a.ldc + n, acc[r] / a.div, a.c_bf16);
+    }
+  }
+}
+
+static constexpr int kBgemmKC = 256;
+static constexpr size_t kBgemmLds = 2 * 64 * (kBgemmKC + 8) * 2;
+hipError_t ops_init() {   // one-time function attributes; call outside any stream capture
+  static bool done = false;
+  if (done) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)k_bgemm_bf16<kBgemmKC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kBgemmLds);
+  if (e == hipSuccess) done = true;
+  return e;
+}
 hipError_t launch_bgemm(const BgemmArgs& a, hipStream_t st) {
   const long long tiles = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;
-  hipLaunchKernelGGL(k_bgemm, dim3((unsigned)tiles), dim3(256), 0, st, a);
+  if (a.a_bf16 || a.b_bf16 || a.c_bf16) {   // bf16 build
+    hipLaunchKernelGGL(k_bgemm_bf16<kBgemmKC>, dim3((unsigned)tiles), dim3(256), kBgemmLds, st, a);
+  } else
+    hipLaunchKernelGGL(k_bgemm, dim3((unsigned)tiles), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -979,6 +979,7 @@ extern "C" int dsx_exec_create(dsx_model* m, int B, int H, int W, int cond_chann
   if (!m->finalized) return fail(DSX_ERR_STATE, "dsx_model_finalize must precede dsx_exec_create");
   if (cond_channels < 0 || cond_channels >= m->cfg.in_channel) return fail(DSX_ERR_INVALID, "bad cond_channels");
   HIP_TRY(conv_init());
+  HIP_TRY(ops_init());
   dsx_exec* ex = new dsx_exec();
   ex->m = m; ex->B = B; ex->H = H; ex->W = W;
   ex->cond_c = cond_channels; ex->x_c = m->cfg.in_channel - cond_channels;
