@@ -25,6 +25,8 @@
 //                  store instruction writes 2 x 128 B contiguous NHWC segments.
 #include "dsx_kernels.h"
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 
 #ifndef DSX_RING_DEPTH
 #define DSX_RING_DEPTH 6  // weight-fragment prefetch ring depth for 3x3 (divides 18)
@@ -101,6 +103,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 
 // diagnostic stamps (DSX_STAMP_OP): wave 0 of one chosen workgroup records s_memtime at phase
 // boundaries into a debug buffer that nothing else reads; off (nullptr) in normal runs
+#ifdef DSX_STAMPS   // diagnostic build (DSX_EXTRA_FLAGS=-DDSX_STAMPS ./build.sh): the checks cost scalar work in hot loops
 #define DSX_STAMP(i)                                                                        \
   do {                                                                                      \
     if (a.stamp != nullptr && blockIdx.x == (unsigned)a.stamp_block && tid == 0 && (i) < 120) \
@@ -112,6 +115,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     if (a.stamp != nullptr && blockIdx.x == (unsigned)a.stamp_block && (cond) && (i) < 128)  \
       a.stamp[(i)] = __builtin_amdgcn_s_memtime();                                          \
   } while (0)
+#else
+#define DSX_STAMP(i) do { } while (0)
+#define DSX_STAMP_T(i, cond) do { } while (0)
+#endif
 
 template <typename DT> struct Chunk;
 template <> struct Chunk<float> { static constexpr int KC = 16; };
@@ -617,6 +624,31 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0F70);  // vmcnt(N) only
 }
 
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <class F, int... I>
+static __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> static __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// MFMA operand fragments of the compute waves are read with explicit ds_read_b128 + counted lgkmcnt waits,
+// PF steps ahead of their MFMAs: left to itself the register-starved scheduler puts every read right before
+// its use ("ds_read; s_waitcnt lgkmcnt(0); v_mfma"), which exposes the LDS latency on every MFMA.
+template <int OFF> static __device__ __forceinline__ void lds_read_frag(f32x4_t& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a, f32x4_t& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a, f32x4_t& b, f32x4_t& c, f32x4_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
 template <typename DT, int MB, int WM, int WN, int KS, int CPG, int D, int NIT, int P, int LW>
 __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) {
   constexpr int LT = 64 * LW;                   // loader threads
@@ -771,52 +803,60 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         baseI = tile_base(posI); flagsI = tile_flags(posI);
       }
     };
-    // raw slot -> GroupNorm affine + Swish -> MFMA image `buf` for item (tiC, gC)
-    auto consume = [&](int slot, int buf) {
-      const int c = gC * (CPG * KC) + cvg * CPU;
+    // Item (tiC, gC) goes raw slot -> registers (fetch) -> GroupNorm affine + Swish -> MFMA image (convert).
+    // The two halves run one iteration apart: the LDS reads of item v+2 are issued before the barrier of
+    // iteration v and are long complete when iteration v+1 converts them (the LDS queue is busy with the
+    // compute waves' operand reads, so a read-then-wait inside one iteration costs hundreds of cycles).
+    constexpr int NA = CPU / 4;          // 16-byte pieces of scale (and of shift) per unit
+    f32x4_t av[2 * NA], rv[NIT];
+    int cF = 0, flagsF = 0;              // channel offset / border flags of the fetched item
+    bool gnF = false;
+    // fetch: scale/shift (parked in LDS by the compute waves -- an ordinary global load here would make the
+    // compiler wait vmcnt(0) and drain the DMA ring) and the raw units of item (tiC, gC); advances (tiC, gC)
+    auto fetch = [&](int slot) {
+      cF = gC * (CPG * KC) + cvg * CPU;
+      flagsF = flagsC;
+      gnF = a.gn_scale != nullptr && cF < C;
       const unsigned src = lds0 + 2 * BUFB + 2 * AFFB + slot * RAWB + ltid * 16;
-      const unsigned dst = lds0 + buf * BUFB;
-      const bool has_gn = a.gn_scale != nullptr && c < C;
-      float sc[CPU], sh[CPU];
-#pragma unroll
-      for (int j = 0; j < CPU; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
-      if (has_gn) {
-        // the compute waves parked this tile's scale/shift in LDS (an ordinary global load here would
-        // make the compiler wait vmcnt(0) and drain the DMA ring)
+      if (gnF) {
         const unsigned af = lds0 + 2 * BUFB + (tiC & 1) * AFFB;
 #pragma unroll
-        for (int q = 0; q < CPU / 4; ++q) {
-          const f32x4_t s4 = lds_read_b128_asm(af + (c + 4 * q) * 4);
-          const f32x4_t h4 = lds_read_b128_asm(af + (C + c + 4 * q) * 4);
-          sc[4 * q] = s4.x; sc[4 * q + 1] = s4.y; sc[4 * q + 2] = s4.z; sc[4 * q + 3] = s4.w;
-          sh[4 * q] = h4.x; sh[4 * q + 1] = h4.y; sh[4 * q + 2] = h4.z; sh[4 * q + 3] = h4.w;
+        for (int q = 0; q < NA; ++q) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(av[q]) : "v"(af + (cF + 4 * q) * 4) : "memory");
+          asm volatile("ds_read_b128 %0, %1" : "=v"(av[NA + q]) : "v"(af + (C + cF + 4 * q) * 4) : "memory");
         }
       }
-      f32x4_t rv[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it)   // all raw reads in flight, one wait
+      for (int it = 0; it < NIT; ++it)
         asm volatile("ds_read_b128 %0, %1" : "=v"(rv[it]) : "v"(src + it * (LT * 16)) : "memory");
-      if constexpr (NIT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0])::"memory");
-      else if constexpr (NIT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1])::"memory");
-      else if constexpr (NIT == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2])::"memory");
-      else if constexpr (NIT == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3])::"memory");
-      else if constexpr (NIT == 5)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4])::"memory");
-      else if constexpr (NIT == 6)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5])::"memory");
-      else if constexpr (NIT == 7)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6])::"memory");
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7])::"memory");
-      static_assert(NIT <= 8, "loader units per thread");
+      if (++gC == G) {
+        gC = 0; ++tiC;
+        tile_advance(posC);
+        flagsC = tile_flags(posC);
+      }
+    };
+    auto convert = [&](int buf) {
+      const unsigned dst = lds0 + buf * BUFB;
+      // the wait, then empty volatile asms that every read's result passes through: volatile asms keep their
+      // order, so no use of a result can be scheduled above the wait
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 2 * NA; ++q) asm volatile("" : "+v"(av[q]));
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rv[it]));
+      float sc[CPU], sh[CPU];
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        sc[4 * q] = av[q].x; sc[4 * q + 1] = av[q].y; sc[4 * q + 2] = av[q].z; sc[4 * q + 3] = av[q].w;
+        sh[4 * q] = av[NA + q].x; sh[4 * q + 1] = av[NA + q].y; sh[4 * q + 2] = av[NA + q].z; sh[4 * q + 3] = av[NA + q].w;
+      }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         if (loff[it] >= 0) {
           float v[CPU];
           Unit<DT>::unpack(__builtin_bit_cast(uint4, rv[it]), v);
-          if ((edge[it] & flagsC) == 0 && c < C) {   // padding pixels stay exactly 0 (padded AFTER the activation)
-            if (has_gn) {
+          if ((edge[it] & flagsF) == 0 && cF < C) {   // padding pixels stay exactly 0 (padded AFTER the activation)
+            if (gnF) {
 #pragma unroll
               for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
             }
@@ -831,39 +871,47 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
           lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, Unit<DT>::pack(v)));
         }
       }
-      if (++gC == G) {
-        gC = 0; ++tiC;
-        tile_advance(posC);
-        flagsC = tile_flags(posC);
-      }
     };
-    // wait until item w's DMAs have landed: only the k = min(P, total-1-w) younger groups may stay in flight
-    auto wait_item = [&](int w) {
-      const int k = min(P, total - 1 - w);
-      if (k >= P) wait_vmcnt<P * NIT>();
-      else if (P > 1 && k == P - 1) wait_vmcnt<(P > 1 ? (P - 1) * NIT : 0)>();
-      else if (P > 2 && k == P - 2) wait_vmcnt<(P > 2 ? (P - 2) * NIT : 0)>();
-      else if (P > 3 && k == P - 3) wait_vmcnt<(P > 3 ? (P - 3) * NIT : 0)>();
+    // wait until the DMAs of the item to fetch have landed; `young` = younger items that may stay in flight
+    auto wait_young = [&](int young) {
+      if (young >= P) wait_vmcnt<P * NIT>();
+      else if (P > 1 && young == P - 1) wait_vmcnt<(P > 1 ? (P - 1) * NIT : 0)>();
+      else if (P > 2 && young == P - 2) wait_vmcnt<(P > 2 ? (P - 2) * NIT : 0)>();
+      else if (P > 3 && young == P - 3) wait_vmcnt<(P > 3 ? (P - 3) * NIT : 0)>();
       else wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
     };
 
-    int issued = 0;
-    for (; issued < NSLOT && issued < total; ++issued) issue(issued % NSLOT);
+    int issued = 0, slotI = 0, slotF = 0;   // items issued; ring slot of the next issue / next fetch
+    auto issue_next = [&]() {
+      issue(slotI);
+      ++issued;
+      if (++slotI == NSLOT) slotI = 0;
+    };
+    auto fetch_next = [&]() {
+      fetch(slotF);
+      if (++slotF == NSLOT) slotF = 0;
+    };
+    while (issued < NSLOT && issued < total) issue_next();
     ws_barrier();                       // scale/shift of tiles 0 and 1 are in LDS
-    wait_item(0);
-    __builtin_amdgcn_sched_barrier(0);
-    consume(0, 0);
-    ws_barrier();
+    wait_young(min(P, total - 1));
+    fetch_next();                       // item 0
+    convert(0);
+    if (total > 1) {
+      wait_young(min(P - 1, total - 2));
+      fetch_next();                     // item 1
+    }
+    ws_barrier();                       // image of item 0 is ready
     DSX_STAMP_T(64, tid == 256);
     for (int v = 0; v < total; ++v) {
-      // slot of item v (its image was built one iteration ago) is free again: reuse it for item v+NSLOT
-      if (issued < total) { issue(issued % NSLOT); ++issued; }
+      // the slot of item v was copied to registers two iterations ago: reuse it for item v+NSLOT
+      if (issued < total) issue_next();
       DSX_STAMP_T(65 + 4 * v, tid == 256 && v < 15);
-      if (v + 1 < total) {
-        wait_item(v + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        DSX_STAMP_T(66 + 4 * v, tid == 256 && v < 15);
-        consume((v + 1) % NSLOT, (v + 1) & 1);
+      if (v + 1 < total) convert((v + 1) & 1);
+      DSX_STAMP_T(66 + 4 * v, tid == 256 && v < 15);
+      if (v + 2 < total) {
+        wait_young(min(P - 1, total - 3 - v));
+        fetch_next();                   // item v+2
       }
       DSX_STAMP_T(67 + 4 * v, tid == 256 && v < 15);
       ws_barrier();
@@ -995,24 +1043,43 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   ws_barrier();   // image of item 0 is ready
   DSX_STAMP_T(0, tid == 0);
   int g = 0, ti = 0;
+  constexpr int PF = 2;                       // operand fragments are read PF steps ahead of their MFMAs
+  static_assert(PF < NSTEP && PF * MB <= 15, "lgkmcnt is 4 bits");
   for (int v = 0; v < total; ++v) {
-    const unsigned char* abuf = lds + (v & 1) * BUFB;
+    unsigned aaddr[MB][KS];                   // LDS byte address of the fragment rows in this item's image
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) aaddr[mb][dy] = lds0 + (v & 1) * BUFB + abase[mb][dy];
+    f32x4_t fb[PF + 1][MB];
+    auto read_step = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int kTapSteps = TAPS * 2;
+      constexpr int cg = s / kTapSteps, tap = (s >> 1) % TAPS, fs = s & 1;
+      constexpr int dy = tap / KS, dx = tap % KS;
+      constexpr int imm = dx * PIXB + cg * 64 + fs * 32;
+      static_assert(imm < 65536, "ds offset field");
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) lds_read_frag<imm>(fb[s % (PF + 1)][mb], aaddr[mb][dy]);
+    };
+    static_for<PF>(read_step);
+    static_for<NSTEP>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
       const uint4 bcur = bq[s % D];
       bq[s % D] = load_b();
-      constexpr int kTapSteps = TAPS * 2;
-      const int cg = s / kTapSteps, tap = (s >> 1) % TAPS, fs = s & 1;
-      const int dy = tap / KS, dx = tap % KS;
-      const int imm = dx * PIXB + cg * 64 + fs * 32;
+      if constexpr (s + PF < NSTEP) read_step(std::integral_constant<int, s + PF>{});
+      constexpr int ahead = (NSTEP - 1 - s < PF ? NSTEP - 1 - s : PF) * MB;   // younger reads that may stay in flight
+      f32x4_t(&cur)[MB] = fb[s % (PF + 1)];
+      if constexpr (MB == 1) wait_frags<ahead>(cur[0]);
+      else if constexpr (MB == 2) wait_frags<ahead>(cur[0], cur[1]);
+      else wait_frags<ahead>(cur[0], cur[1], cur[2], cur[3]);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const uint4 av = *(const uint4*)(abuf + abase[mb][dy] + imm);
         if constexpr (IS_BF16) {
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur),
-                                                            __builtin_bit_cast(bf16x8, av), acc[mb], 0, 0, 0);
+                                                            __builtin_bit_cast(bf16x8, cur[mb]), acc[mb], 0, 0, 0);
         } else {
-          const float4 af = __builtin_bit_cast(float4, av);
+          const float4 af = __builtin_bit_cast(float4, cur[mb]);
           const float4 bf = __builtin_bit_cast(float4, bcur);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc[mb], 0, 0, 0);
@@ -1020,7 +1087,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc[mb], 0, 0, 0);
         }
       }
-    }
+    });
     DSX_STAMP_T(1 + 3 * v, tid == 0 && v < 20);
     ws_barrier();   // the loaders may now overwrite this image; the next one is complete
     DSX_STAMP_T(2 + 3 * v, tid == 0 && v < 20);
