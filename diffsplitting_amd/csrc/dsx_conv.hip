@@ -28,6 +28,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef DSX_LOADER_PRIO
+#define DSX_LOADER_PRIO 1
+#endif
 #ifndef DSX_RING_DEPTH
 #define DSX_RING_DEPTH 6  // weight-fragment prefetch ring depth for 3x3 (divides 18)
 #endif
@@ -722,6 +725,10 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 
   if (loader) {
     // ======================================================================= LOADER WAVES
+    // The loader waves are dispatched after the compute waves, and vector issue on a SIMD is arbitrated by
+    // priority, then age: as the younger wave their GroupNorm/Swish VALU stream only gets the slots the MFMA
+    // wave leaves over, and they become the critical path.  Static priority for the whole kernel.
+    __builtin_amdgcn_s_setprio(DSX_LOADER_PRIO);
     // Per-thread, tile-invariant description of its NIT units: LDS image offset, source pixel offset
     // relative to the tile's origin pixel, and which patch borders the unit lies on.  Per tile only the
     // origin offset and four "tile touches the image border" flags change (no divisions, no per-unit
@@ -839,11 +846,13 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       const unsigned dst = lds0 + buf * BUFB;
       // the wait, then empty volatile asms that every read's result passes through: volatile asms keep their
       // order, so no use of a result can be scheduled above the wait
+      DSX_STAMP_T(120, tid == 256 && tiC == 2 && gC == 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int q = 0; q < 2 * NA; ++q) asm volatile("" : "+v"(av[q]));
 #pragma unroll
       for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rv[it]));
+      DSX_STAMP_T(121, tid == 256 && tiC == 2 && gC == 0);
       float sc[CPU], sh[CPU];
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
@@ -868,9 +877,11 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #pragma unroll
             for (int j = 0; j < CPU; ++j) v[j] = 0.f;
           }
+          if (it == NIT - 1) { asm volatile("" :: "v"(v[0]), "v"(v[CPU - 1])); DSX_STAMP_T(122, tid == 256 && tiC == 2 && gC == 0); }
           lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, Unit<DT>::pack(v)));
         }
       }
+      DSX_STAMP_T(123, tid == 256 && tiC == 2 && gC == 0);
     };
     // wait until the DMAs of the item to fetch have landed; `young` = younger items that may stay in flight
     auto wait_young = [&](int young) {

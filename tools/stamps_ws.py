@@ -46,3 +46,6 @@ eps = [v for v in range(20) if st[3 + 3*v] > 0 and st[1 + 3*v] > 0]
 if len(eps) >= 2 and st[61] > 0:
     v = eps[1]; b, e = st[2 + 3*v], st[3 + 3*v]
     print("epilogue of tile 1: load_aff %d | loads+adds+stores %d | stats %d" % (st[61] - b, st[62] - st[61], e - st[62]))
+
+if st[120] > 0:
+    print("convert breakdown (one item): lds-wait %d | math %d | writes+drain %d" % (st[121]-st[120], st[122]-st[121], st[123]-st[122]))
