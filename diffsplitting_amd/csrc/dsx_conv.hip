@@ -1,5 +1,6 @@
 // dsx_conv.hip — fused GroupNorm-apply + Swish + KxK convolution (+bias +FiLM
-// +residual) as an implicit GEMM on gfx950 MFMA, NHWC fp32 activations in HBM.
+// +residual) as an implicit GEMM on gfx950 MFMA; NHWC activations in HBM in the MFMA operand type
+// (fp32 in the parity build, bf16 in the bf16 build).
 //
 // Replaces the ATen op chain of Block / ResnetBlock / Upsample / Downsample /
 // 1x1 convs of the reference UNets (model/sr3_modules/unet.py:58-110,
@@ -10,7 +11,7 @@
 //   output tile  : BM = TB x TH x TW output pixels  x  BN output channels
 //   K loop       : chunks of 64 B of input channels per pixel (16 fp32 / 32 bf16)
 //   A operand    : the (TH*S+KS-S) x (TW*S+KS-S) input halo patch of the chunk is
-//                  loaded once (coalesced float4 along C), normalised + activated
+//                  loaded once (coalesced 16-byte units along C), normalised + activated
 //                  in registers, converted, and parked in LDS with an 80-B pixel
 //                  stride (conflict-free ds_read_b128); all KS*KS taps re-read it
 //                  at constant LDS offsets -> 9x fewer global reads than im2col.
@@ -21,8 +22,8 @@
 //   MFMA         : bf16  v_mfma_f32_32x32x16_bf16 (1 per 16-B fragment pair)
 //                  fp32  v_mfma_f32_32x32x2_f32   (4 per 16-B fragment pair; exact
 //                        fp32 FMA chain -> the <=1e-3 parity path)
-//   epilogue     : accumulator rows are pixels, columns are channels -> each
-//                  store instruction writes 2 x 128 B contiguous NHWC segments.
+//   epilogue     : weights are the MFMA A operand (rows packed permuted), pixels the B operand: a lane
+//                  holds one pixel x 16 consecutive channels -> 16-byte loads / NHWC stores only.
 #include "dsx_kernels.h"
 #include <algorithm>
 #include <type_traits>
@@ -591,9 +592,10 @@ __global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1
 // (L2, ~0.6 us) share ONE in-order vmcnt queue, so neither can be prefetched deeper than the other
 // allows, and every phase of k_conv_mfma (load wait, GN+Swish VALU, MFMA, epilogue) ends up serialised.
 // Here a workgroup is 8 waves:
-//   waves 4-7  LOADERS : LDS-DMA (buffer_load ... lds, no VGPRs) of the raw fp32 halo patch P groups
-//                        ahead into a ring, then GroupNorm affine + Swish + convert and the MFMA image
-//                        of the NEXT group; their vmcnt only ever counts activation DMAs.
+//   waves 4-7  LOADERS : LDS-DMA (buffer_load ... lds, no VGPRs) of the raw halo patch P groups ahead
+//                        into a ring; units are read back one iteration before use, then GroupNorm
+//                        affine + Swish + convert and the MFMA image of the NEXT group; their vmcnt
+//                        only ever counts activation DMAs.  s_setprio 1 (see below).
 //   waves 0-3  COMPUTE : weight-fragment ring + MFMA on the CURRENT group's image, epilogue + fused
 //                        statistics at tile ends; their vmcnt only counts weight / epilogue loads.
 // Both pipes of a SIMD stay busy (one loader + one compute wave per SIMD: VALU beside MFMA), the
