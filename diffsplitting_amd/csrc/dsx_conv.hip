@@ -654,7 +654,7 @@ template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a, f
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 
-template <typename DT, int MB, int WM, int WN, int KS, int CPG, int D, int NIT, int P, int LW>
+template <typename DT, int MB, int WM, int WN, int NB, int KS, int CPG, int D, int NIT, int P, int LW>
 __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) {
   constexpr int LT = 64 * LW;                   // loader threads
   constexpr int S = 1;
@@ -934,6 +934,9 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   }
 
   // ========================================================================= COMPUTE WAVES
+  // Each wave owns MB row blocks x NB 32-channel N blocks.  With NB = 2 a pixel fragment read from LDS
+  // feeds two MFMAs (LDS operand traffic per MFMA halves) and one converted group of the loaders feeds twice
+  // the MFMA work.
   const int wm = wave / WN, wn = wave % WN;
   int abase[MB][KS];
 #pragma unroll
@@ -946,31 +949,36 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     for (int dy = 0; dy < KS; ++dy)
       abase[mb][dy] = (tb * PH + ty * S + dy) * RB + tx * S * PIXB + lh * 16;
   }
-  const int blk = nt * WN + wn;                 // host: Cout % (32 * WN) == 0, so every block exists
-  const long long wblock = (long long)G * (NSTEP * 1024);
+  const int blk0 = (nt * WN + wn) * NB;         // host: Cout % (32 * WN * NB) == 0, so every block exists
+  const int wblock = G * (NSTEP * 1024);        // bytes of one N block's fragment stream
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const unsigned char*)a.wpack + (size_t)blk * wblock), 0, (int)wblock, 0x00020000);
+      (void*)((const unsigned char*)a.wpack + (size_t)blk0 * wblock), 0, NB * wblock, 0x00020000);
   const int wlane = lane * 16;
-  const int qtot = G * NSTEP;                   // the stream restarts at every tile (same N block)
+  const int qtot = G * NSTEP;                   // the stream restarts at every tile (same N blocks)
   int qn = 0;                                   // next step to prefetch (wraps)
-  auto load_b = [&]() -> uint4 {
-    const uint4 r = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, qn * 1024, 0));
+  struct WFrag { uint4 v[NB]; };                // one step's weight fragments (by value: stays in registers)
+  auto load_b = [&]() -> WFrag {
+    WFrag f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      f.v[nb] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, nb * wblock + qn * 1024, 0));
     if (++qn == qtot) qn = 0;
-    return r;
+    return f;
   };
-  uint4 bq[D];
+  WFrag bq[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) bq[j] = load_b();
 
-  f32x16 acc[MB];
+  f32x16 acc[MB][NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
-  constexpr bool STATS = MB <= 4;   // 256 VGPRs per wave here: the statistics fit in every tile
-  const bool do_stats = STATS && a.stat_part != nullptr;
-  const int nbase = blk * 32 + 16 * lh;         // this lane's 16 consecutive channels
+  const bool do_stats = a.stat_part != nullptr;
+  const int nbase = blk0 * 32 + 16 * lh;        // this lane's 16 consecutive channels of N block 0 (+32 per block)
 
   // Tile walk without divisions: (tx, ty, image) of tile p0 + k*wpn, advanced by the decomposed stride.
   struct TilePos { int tx, ty, b; };
@@ -1014,35 +1022,45 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 
   // Epilogue operands live in registers and are fetched one tile ahead, at the start of the previous tile's
   // epilogue (right after its own operands were consumed): the loads then have the rest of that epilogue
-  // plus the 18 ring steps to land before an in-order vmcnt wait of the weight ring can trip over them.
-  // Bias is fetched once (the workgroup never changes its N tile).  Missing operands stay 0.0f: exact.
+  // plus the ring's steps to land before an in-order vmcnt wait of the weight ring can trip over them.
+  // One per-channel addend: the FiLM vector of the tile's image (the host folds the conv bias into the FiLM
+  // bias, see dsx_model_finalize) or, without FiLM, the conv bias, fetched once (the workgroup never changes
+  // its N tile).  Missing operands stay 0.0f: adding them is exact.
   constexpr int NR = 16 / CPU;   // 16-byte pieces of a lane's 16 residual values
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 biasv[4], filmv[4], affv[2];
-  uint4 residv[MB][NR];          // storage type; all-zero bits are 0.0 in both
+  float4 addv[NB][4], affv[2];
+  constexpr bool PRE_RESID = NB == 1;   // with two N blocks per wave the residual no longer fits: read in the epilogue
+  uint4 residv[PRE_RESID ? MB : 1][NB][NR];      // storage type; all-zero bits are 0.0 in both
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    biasv[j] = a.bias ? *(const float4*)(a.bias + nbase + 4 * j) : zero4;
-    filmv[j] = zero4;
-  }
+  for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+    for (int j = 0; j < 4; ++j)
+      addv[nb][j] = (a.bias && !a.film) ? *(const float4*)(a.bias + nbase + 32 * nb + 4 * j) : zero4;
 #pragma unroll
-    for (int q = 0; q < NR; ++q) residv[mb][q] = make_uint4(0u, 0u, 0u, 0u);
+  for (int mb = 0; mb < (PRE_RESID ? MB : 1); ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < NR; ++q) residv[mb][nb][q] = make_uint4(0u, 0u, 0u, 0u);
   affv[0] = affv[1] = zero4;
   // t: the tile whose epilogue will use the operands; b_aff: image of the tile two after it
   auto prefetch_epilogue = [&](const TilePos& t, bool want_aff, int b_aff) {
     if (a.film) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) filmv[j] = *(const float4*)(a.film + (size_t)t.b * a.film_bs + nbase + 4 * j);
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          addv[nb][j] = *(const float4*)(a.film + (size_t)t.b * a.film_bs + nbase + 32 * nb + 4 * j);
     }
-    if (a.resid) {
+    if (PRE_RESID && a.resid) {
       const int r0 = tile_pixel0(t) * a.resid_ld;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
+      for (int mb = 0; mb < (PRE_RESID ? MB : 1); ++mb) {
         const DT* rp = (const DT*)a.resid + (r0 + rrow[mb]);
 #pragma unroll
-        for (int q = 0; q < NR; ++q) residv[mb][q] = *(const uint4*)(rp + CPU * q);
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int q = 0; q < NR; ++q) residv[mb][nb][q] = *(const uint4*)(rp + 32 * nb + CPU * q);
       }
     }
     if (want_aff && a.gn_scale != nullptr && tid * 4 < C) {
@@ -1056,7 +1074,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   ws_barrier();   // image of item 0 is ready
   DSX_STAMP_T(0, tid == 0);
   int g = 0, ti = 0;
-  constexpr int PF = 2;                       // operand fragments are read PF steps ahead of their MFMAs
+  constexpr int PF = NB == 2 ? 1 : 2;         // operand fragments are read PF steps ahead of their MFMAs (a step is NB x longer)
   static_assert(PF < NSTEP && PF * MB <= 15, "lgkmcnt is 4 bits");
   for (int v = 0; v < total; ++v) {
     unsigned aaddr[MB][KS];                   // LDS byte address of the fragment rows in this item's image
@@ -1078,28 +1096,32 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     static_for<PF>(read_step);
     static_for<NSTEP>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      const uint4 bcur = bq[s % D];
+      const WFrag bcur = bq[s % D];
+#ifndef DSX_ABL_W   // -DDSX_ABL_W: timing experiment, weight stream off (results wrong)
       bq[s % D] = load_b();
+#endif
       if constexpr (s + PF < NSTEP) read_step(std::integral_constant<int, s + PF>{});
       constexpr int ahead = (NSTEP - 1 - s < PF ? NSTEP - 1 - s : PF) * MB;   // younger reads that may stay in flight
-      f32x4_t(&cur)[MB] = fb[s % (PF + 1)];
-      if constexpr (MB == 1) wait_frags<ahead>(cur[0]);
-      else if constexpr (MB == 2) wait_frags<ahead>(cur[0], cur[1]);
-      else wait_frags<ahead>(cur[0], cur[1], cur[2], cur[3]);
+      constexpr int cb = s % (PF + 1);
+      if constexpr (MB == 1) wait_frags<ahead>(fb[cb][0]);
+      else if constexpr (MB == 2) wait_frags<ahead>(fb[cb][0], fb[cb][1]);
+      else wait_frags<ahead>(fb[cb][0], fb[cb][1], fb[cb][2], fb[cb][3]);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        if constexpr (IS_BF16) {
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur),
-                                                            __builtin_bit_cast(bf16x8, cur[mb]), acc[mb], 0, 0, 0);
-        } else {
-          const float4 af = __builtin_bit_cast(float4, cur[mb]);
-          const float4 bf = __builtin_bit_cast(float4, bcur);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af.z, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc[mb], 0, 0, 0);
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          if constexpr (IS_BF16) {
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur.v[nb]),
+                                                                  __builtin_bit_cast(bf16x8, fb[cb][mb]), acc[mb][nb], 0, 0, 0);
+          } else {
+            const float4 af = __builtin_bit_cast(float4, fb[cb][mb]);
+            const float4 bf = __builtin_bit_cast(float4, bcur.v[nb]);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af.z, acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc[mb][nb], 0, 0, 0);
+          }
         }
-      }
     });
     DSX_STAMP_T(1 + 3 * v, tid == 0 && v < 20);
     ws_barrier();   // the loaders may now overwrite this image; the next one is complete
@@ -1115,26 +1137,32 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       *(float4*)(dst + tid * 4) = affv[0];
       *(float4*)(dst + C + tid * 4) = affv[1];
     }
-    // reference order: conv -> + bias -> + FiLM -> + residual
+    // conv -> + (bias | FiLM incl. bias) -> + residual
+    const int rcur = PRE_RESID ? 0 : tile_pixel0(cur) * a.resid_ld;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      float rs[16];
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int q = 0; q < NR; ++q) {
-        float t[CPU];
-        Unit<DT>::unpack(residv[mb][q], t);
+      for (int nb = 0; nb < NB; ++nb) {
+        float rs[16];
 #pragma unroll
-        for (int j = 0; j < CPU; ++j) rs[CPU * q + j] = t[j];
+        for (int q = 0; q < NR; ++q) {
+          float t[CPU];
+          uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+          if constexpr (PRE_RESID) rr = residv[mb][nb][q];
+          else if (a.resid) rr = *(const uint4*)((const DT*)a.resid + (rcur + rrow[mb]) + 32 * nb + CPU * q);
+          Unit<DT>::unpack(rr, t);
+#pragma unroll
+          for (int j = 0; j < CPU; ++j) rs[CPU * q + j] = t[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 ta = addv[nb][j];
+          acc[mb][nb][4 * j + 0] = (acc[mb][nb][4 * j + 0] + ta.x) + rs[4 * j + 0];
+          acc[mb][nb][4 * j + 1] = (acc[mb][nb][4 * j + 1] + ta.y) + rs[4 * j + 1];
+          acc[mb][nb][4 * j + 2] = (acc[mb][nb][4 * j + 2] + ta.z) + rs[4 * j + 2];
+          acc[mb][nb][4 * j + 3] = (acc[mb][nb][4 * j + 3] + ta.w) + rs[4 * j + 3];
+        }
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 tb = biasv[j], tf = filmv[j];
-        acc[mb][4 * j + 0] = ((acc[mb][4 * j + 0] + tb.x) + tf.x) + rs[4 * j + 0];
-        acc[mb][4 * j + 1] = ((acc[mb][4 * j + 1] + tb.y) + tf.y) + rs[4 * j + 1];
-        acc[mb][4 * j + 2] = ((acc[mb][4 * j + 2] + tb.z) + tf.z) + rs[4 * j + 2];
-        acc[mb][4 * j + 3] = ((acc[mb][4 * j + 3] + tb.w) + tf.w) + rs[4 * j + 3];
-      }
-    }
     DSX_STAMP_T(61, tid == 0 && ti == 1);
     // the operand registers are free again: fetch the next tile's (and the scale/shift of tile ti+3)
     const TilePos done = cur;
@@ -1142,39 +1170,38 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     cur = nxt; nxt = nn; tile_advance(nn);
     if (ti < ntile) prefetch_epilogue(cur, ti + 2 < ntile, nn.b);
 
-    float s1[16], s2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
     const int o0 = tile_pixel0(done) * a.out_ld;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      {
+    for (int nb = 0; nb < NB; ++nb) {
+      float s1[16], s2[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
         float x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = acc[mb][r];
-        store16<true>(a.out, (size_t)(o0 + orow[mb]), x, IS_BF16, 16);   // host: out is in the storage type
-      }
-      if constexpr (STATS) {
+        for (int r = 0; r < 16; ++r) x[r] = acc[mb][nb][r];
+        store16<true>(a.out, (size_t)(o0 + orow[mb] + 32 * nb), x, IS_BF16, 16);   // host: out is in the storage type
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s1[r] += acc[mb][r]; s2[r] += acc[mb][r] * acc[mb][r]; }
-      }
+        for (int r = 0; r < 16; ++r) { s1[r] += x[r]; s2[r] += x[r] * x[r]; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+      }
+      if (do_stats) {
+        // lane (li & 15) holds register row16_fold_reg(li), summed over its 16 pixels; add the other row's copy
+        float w1 = row16_fold(s1, lane), w2 = row16_fold(s2, lane);
+        w1 += __shfl_xor(w1, 16, 64);
+        w2 += __shfl_xor(w2, 16, 64);
+        const int chunk = (done.ty * a.tiles_x + done.tx) * WM + wm;
+        const int nch = per_img * WM;
+        const int n = nbase + 32 * nb + row16_fold_reg(li);
+        if (li < 16) {
+          float* pp = a.stat_part + (((size_t)done.b * nch + chunk) * a.Cout + n) * 2;
+          pp[0] = w1; pp[1] = w2;
+        }
+      }
     }
     DSX_STAMP_T(62, tid == 0 && ti == 2);
-    if (do_stats) {
-      // lane (li & 15) holds register row16_fold_reg(li), summed over its 16 pixels; add the other row's copy
-      float w1 = row16_fold(s1, lane), w2 = row16_fold(s2, lane);
-      w1 += __shfl_xor(w1, 16, 64);
-      w2 += __shfl_xor(w2, 16, 64);
-      const int chunk = (done.ty * a.tiles_x + done.tx) * WM + wm;
-      const int nch = per_img * WM;
-      const int n = nbase + row16_fold_reg(li);
-      if (li < 16) {
-        float* pp = a.stat_part + (((size_t)done.b * nch + chunk) * a.Cout + n) * 2;
-        pp[0] = w1; pp[1] = w2;
-      }
-    }
     DSX_STAMP_T(3 + 3 * v, tid == 0 && v < 20);
   }
 }
@@ -1197,7 +1224,9 @@ ConvTileInfo conv_tile_info(int tile) {
 
 int conv_tile_wm(int tile) { return kTiles[tile].WM; }
 bool conv_tile_fuses_stats(int tile) { return kTiles[tile].MB <= 2; }
-bool conv_ws_fuses_stats(int tile) { return kTiles[tile].MB <= 4; }
+bool conv_ws_fuses_stats(int tile) {
+  return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;
+}
 
 static constexpr int conv_cpg(int ks) { return ks == 1 ? 2 : 1; }
 
@@ -1286,10 +1315,19 @@ hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& 
                     : launch_dt<float>(tile, ks, stride, &a, lds, st);
 }
 
-// ---- warp-specialised variant: per (dtype, tile, ks) constants
+// ---- warp-specialised variant: per (dtype, tile, ks) constants.  Its waves are laid out differently from
+// k_conv_mfma's: MB row blocks x NB N blocks per wave (the 128 x 128 tile is 2 x 2 waves of 64 x 64).
+struct WsTileCfg { int MB, WM, WN, NB; };
+static constexpr WsTileCfg ws_tile(int tile) {
+  return tile == TILE_128x128 ? WsTileCfg{2, 2, 2, 2}
+       : tile == TILE_64x128  ? WsTileCfg{2, 1, 4, 1}
+       : tile == TILE_128x64  ? WsTileCfg{2, 2, 2, 1}
+                              : WsTileCfg{1, 2, 2, 1};   // TILE_64x64
+}
 static constexpr bool ws_tile_ok(int tile) {
   return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;
 }
+int conv_ws_tile_wm(int tile) { return ws_tile(tile).WM; }
 static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activations in flight beyond the current one
   const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
   return bm == 64 ? 4 : (ks == 1 ? 2 : 3);
@@ -1308,6 +1346,7 @@ static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units pe
 }
 size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   if (!ws_tile_ok(tile) || !(ks == 1 || ks == 3)) return 0;
+  if (ws_tile(tile).NB == 2 && dtype != 1) return 0;
   if (conv_lds_bytes(dtype, tile, ks, 1, a) == 0) return 0;
   if (patch_pixels(ks, 1, a) > ws_max_px(tile, ks)) return 0;
   if (a.up && (a.tw_log2 == 0 || a.th_log2 == 0)) return 0;   // the loaders assume an even tile origin when upsampling
@@ -1320,22 +1359,25 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
   if ((long long)a.B * a.Ho * a.Wo * std::max(a.out_ld, a.resid_ld) >= (1LL << 31)) return 0;   // 32-bit element offsets
   const int al = dtype == 1 ? 7 : 3;   // 16-byte rows in elements of the storage type
-  if (a.Cout % (32 * kTiles[tile].WN) != 0 || (a.out_ld & al) != 0 || (a.resid_ld & al) != 0 || a.C0 + a.C1 > 1024) return 0;
+  if (a.Cout % (32 * ws_tile(tile).WN * ws_tile(tile).NB) != 0 || (a.out_ld & al) != 0 || (a.resid_ld & al) != 0 ||
+      a.C0 + a.C1 > 1024)
+    return 0;
   if (dtype == 1 && !(a.act_bf16 && a.out_bf16)) return 0;   // this kernel reads and writes the storage type only
   return total <= 160 * 1024 ? total : 0;
 }
 
 template <typename DT, int TILE, int KS>
 static hipError_t launch_ws_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
-  if constexpr (!ws_tile_ok(TILE)) {
-    return hipErrorInvalidValue;
+  if constexpr (!ws_tile_ok(TILE) || (ws_tile(TILE).NB == 2 && sizeof(DT) == 4)) {
+    return ap ? hipErrorInvalidValue : hipSuccess;   // (the fp32 build has no two-N-block variant: registers)
   } else {
-    constexpr TileCfg t = kTiles[TILE];
+    constexpr WsTileCfg t = ws_tile(TILE);
     constexpr int CPG = conv_cpg(KS);
-    constexpr int D = KS == 1 ? 4 : 18;   // full-group weight ring (3 waves/SIMD: 168 registers per thread)
+    // weight ring, in steps: a full group for one N block per wave, half of it (same bytes, same time) for two
+    constexpr int D = KS == 1 ? 4 : (t.NB == 2 ? 6 : 18);
     constexpr int NIT = ws_nit(sizeof(DT) == 2 ? 1 : 0, TILE, KS);
     constexpr int P = ws_depth(TILE, KS);
-    auto kern = k_conv_ws<DT, t.MB, t.WM, t.WN, KS, CPG, D, NIT, P, kWsLoaderWaves>;
+    auto kern = k_conv_ws<DT, t.MB, t.WM, t.WN, t.NB, KS, CPG, D, NIT, P, kWsLoaderWaves>;
     if (!ap)
       return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const ConvArgs& a = *ap;
@@ -1360,6 +1402,7 @@ static hipError_t launch_ws_dt(int tile, int ks, const ConvArgs* a, size_t lds, 
 hipError_t launch_conv_ws(int dtype, int tile, int ks, const ConvArgs& a, hipStream_t st) {
   const size_t lds = conv_ws_lds_bytes(dtype, tile, ks, a);
   if (lds == 0 || a.ksplit != 1 || a.ws_wg_per_n < 1 || a.stage_mode != 0) return hipErrorInvalidValue;
+  if (a.bias && a.film) return hipErrorInvalidValue;   // the planner folds the conv bias into the FiLM bias
   return dtype == 1 ? launch_ws_dt<__bf16>(tile, ks, &a, lds, st) : launch_ws_dt<float>(tile, ks, &a, lds, st);
 }
 

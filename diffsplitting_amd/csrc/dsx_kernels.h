@@ -60,6 +60,7 @@ ConvTileInfo conv_tile_info(int tile);
 int conv_tile_wm(int tile);   // waves along M (one statistics row per (tile, wm))
 bool conv_tile_fuses_stats(int tile);   // k_conv_mfma
 bool conv_ws_fuses_stats(int tile);     // k_conv_ws
+int conv_ws_tile_wm(int tile);          // k_conv_ws lays its waves out differently
 // input-channel chunks are staged in groups of this many (weights are packed/padded to it)
 int conv_chunk_multiple(int ks);
 int conv_lds_row(int ks, int stride, int tw_log2);

@@ -413,6 +413,10 @@ extern "C" int dsx_model_finalize(dsx_model* m, int dtype) {
       memcpy(wf.data() + (size_t)md.film_off * inner, m->params[md.film.pw].host.data(),
              (size_t)md.cout * inner * 4);
       memcpy(bf.data() + md.film_off, m->params[md.film.pb].host.data(), (size_t)md.cout * 4);
+      // the FiLM vector is only ever added to conv1's output: carry conv1's bias in it (one per-channel addend
+      // in the conv epilogue instead of two; plan_res passes no bias for that conv)
+      if (md.conv1.pb >= 0)
+        for (int n = 0; n < md.cout; ++n) bf[md.film_off + n] += m->params[md.conv1.pb].host[n];
     }
   }
   if (m->cfg.with_time_emb) {
@@ -614,9 +618,9 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   // tile (least re-staging of the activations per output channel) that still gives >= ws_min work items.
   static const int ws_on = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
   static const int ws_min = getenv("DSX_WS_MIN_GRID") ? atoi(getenv("DSX_WS_MIN_GRID")) : 224;
-  // 3x3: the 64-pixel tile (two MFMAs per weight fragment keeps LDS and L1 in balance); 1x1: the 128-pixel tile
-  // (no tap reuse of the image, so the longer MFMA run per barrier wins)
-  static const std::vector<int> ws_wide3 = tile_order("DSX_TILES_WS_WIDE", {TILE_64x128, TILE_128x128});
+  // the 128 x 128 tile (2 x 2 waves of 64 pixels x 64 channels: each LDS pixel fragment feeds two MFMAs and each
+  // converted group twice the MFMA work of the 64 x 128 tile) wherever it still fills the chip
+  static const std::vector<int> ws_wide3 = tile_order("DSX_TILES_WS_WIDE", {TILE_128x128, TILE_64x128});
   static const std::vector<int> ws_wide1 = tile_order("DSX_TILES_WS_WIDE_1X1", {TILE_128x128, TILE_64x128});
   const std::vector<int>& ws_wide = ks == 1 ? ws_wide1 : ws_wide3;
   static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_128x64, TILE_64x64});
@@ -671,6 +675,7 @@ struct ConvSpec {
   const void* resid = nullptr; int resid_ld = 0;
   Tensor out;
   bool want_stats = false;   // a GroupNorm will read `out`: produce its statistics in the epilogue
+  bool bias_in_film = false; // the conv bias is already part of the FiLM vector (dsx_model_finalize)
 };
 
 static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
@@ -688,7 +693,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
     const int um = ex->m->dtype == 1 ? 7 : 3;                                       // channels per 16-byte unit - 1
     a.stage_mode = ((a.C0 & um) || (a.C1 & um)) ? 2 : ((a.C1 == 0 || a.C0 % gw == 0) ? 0 : 1);
   }
-  a.wpack = s.w->pack; a.bias = s.w->bias;
+  a.wpack = s.w->pack; a.bias = s.bias_in_film ? nullptr : s.w->bias;
   a.film = s.film; a.film_bs = s.film_bs;
   a.resid = s.resid; a.resid_ld = s.resid_ld;
   a.out = s.out.p; a.out_ld = s.out.C; a.Cout = s.w->cout;
@@ -707,7 +712,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       (a.Cout & 15) == 0 &&
       a.out_ld == a.Cout && (a.resid_ld & 7) == 0) {
     StatInfo& si = ex->stats[s.out.id];
-    si.nchunk = a.tiles_x * a.tiles_y * conv_tile_wm(tile);
+    si.nchunk = a.tiles_x * a.tiles_y * (use_ws ? conv_ws_tile_wm(tile) : conv_tile_wm(tile));
     si.part = ws_alloc(ex, (size_t)a.B * si.nchunk * a.Cout * 2 * sizeof(float));
     si.planned = true;
     si.f32 = true;
@@ -846,6 +851,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   c1.w = &md.conv1; c1.x0 = x0; if (x1) c1.x1 = *x1;
   c1.gn_scale = s1; c1.gn_shift = h1; c1.has_gn = true; c1.swish = true;
   if (md.film_off >= 0 && !ex->sizing) { c1.film = ex->film + md.film_off; c1.film_bs = ex->m->F; }
+  c1.bias_in_film = md.film_off >= 0 && md.conv1.pb >= 0;
   c1.out = h; c1.want_stats = true;
   if ((rc = plan_conv(ex, c1))) return rc;
   plan_gn(ex, md.gn2, h, nullptr, &s2, &h2);
