@@ -55,6 +55,7 @@ SIGNATURES = {
     "dsx_exec_num_ops": (_i, [_vp]),
     "dsx_exec_op_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dsx_exec_profile": (_i, [_vp, _i, _vp, _vp]),
+    "dsx_exec_time_kind": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "dsx_exec_read_stamps": (_i, [_vp, _vp]),
     "dsx_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "dsx_time_predictor_set_mask": (_i, [_vp, _vp, _vp]),

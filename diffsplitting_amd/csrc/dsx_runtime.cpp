@@ -1032,6 +1032,44 @@ extern "C" int dsx_exec_op_info(const dsx_exec* ex, int i, char* desc, int cap, 
   return DSX_OK;
 }
 // diagnostics: copy the 128 in-kernel stamps of the launch chosen with DSX_STAMP_OP (zeros if none)
+extern "C" int dsx_exec_time_kind(dsx_exec* ex, int kind, int iters, float* ms_per_replay, int* launches,
+                                  void* stream) {
+  if (!ex || !ms_per_replay || iters < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!st) return fail(DSX_ERR_INVALID, "dsx_exec_time_kind needs a non-default stream (stream capture)");
+  int n = 0;
+  for (auto& oi : ex->op_info) n += oi.kind == kind ? 1 : 0;
+  if (launches) *launches = n;
+  if (n == 0) { *ms_per_replay = 0.f; return DSX_OK; }
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  hipError_t err = hipSuccess;
+  for (size_t i = 0; i < ex->ops.size() && err == hipSuccess; ++i)
+    if (ex->op_info[i].kind == kind) err = ex->ops[i](st);
+  hipError_t e2 = hipStreamEndCapture(st, &graph);
+  if (err != hipSuccess || e2 != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return fail(DSX_ERR_HIP, "capture of the kernel family failed: %s", hipGetErrorString(err != hipSuccess ? err : e2));
+  }
+  HIP_TRY(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipGraphLaunch(gexec, st));   // warm-up replay
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int it = 0; it < iters; ++it) HIP_TRY(hipGraphLaunch(gexec, st));
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_replay = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(gexec); (void)hipGraphDestroy(graph);
+  return DSX_OK;
+}
+
 extern "C" int dsx_exec_read_stamps(dsx_exec* ex, unsigned long long* out128) {
   if (!ex || !out128) return fail(DSX_ERR_INVALID, "null argument");
   memset(out128, 0, 128 * 8);

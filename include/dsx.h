@@ -110,6 +110,12 @@ int dsx_exec_num_ops(const dsx_exec* ex);
 int dsx_exec_op_info(const dsx_exec* ex, int index, char* desc_buf, int desc_cap, int* kind,
                      double* flops, double* bytes);
 int dsx_exec_profile(dsx_exec* ex, int iters, float* ms_per_op, void* stream);
+/* The launches of one kind (DSX_OP_*) captured into a hipGraph of their own and replayed `iters` times
+ * between two hipEvents on `stream`: *ms_per_replay is the time of one back-to-back pass over them, i.e.
+ * what `rocprofv3 --kernel-trace` sums for that kernel family inside the captured sampling step (the eager
+ * per-launch times of dsx_exec_profile additionally contain the launch gaps). Inputs are whatever the
+ * workspace holds; the timing of these kernels does not depend on the data. */
+int dsx_exec_time_kind(dsx_exec* ex, int kind, int iters, float* ms_per_replay, int* launches, void* stream);
 /* diagnostics: in-kernel phase stamps (s_memtime) of the conv launch selected by DSX_STAMP_OP */
 int dsx_exec_read_stamps(dsx_exec* ex, unsigned long long* out128);
 

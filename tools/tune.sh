@@ -10,7 +10,7 @@ l = sys.argv[1]
 try:
     d = json.load(open(f"gpurun_out/tune_{l}.json"))
     r = d["roofline"]
-    print(f"{l:24s} ms/step {d['ms_per_step']:.3f}  img/s {d['value']:.3f}  conv {r['conv_ms_per_step']:.3f} ms @ {r['achieved']:.0f} TF/s  all-kernels {r['all_kernels_ms_per_step']:.3f}")
+    print(f"{l:24s} ms/step {d['ms_per_step']:.3f}  img/s {d['value']:.3f}  conv {r['conv_ms_per_step']:.3f} ms @ {r['achieved']:.0f} TF/s  all-kernels(eager) {r['all_kernels_ms_per_step_eager_events']:.3f}")
 except Exception as e:
     print(l, "FAILED", e); print(open(f"gpurun_out/tune_{l}.err").read()[-800:])
 PY
