@@ -133,6 +133,10 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
       for (int u = 0; u < 8; ++u) { s += ps[u]; q += pq[u]; }
     }
   };
+  // gamma / beta of this lane's channel: issued with the partial sums (one memory round trip, not two)
+  const int c_own = c_lo + lane;
+  const bool own = lane < cpg;
+  const float g_own = own ? a.gamma[c_own] : 0.f, b_own = own ? a.beta[c_own] : 0.f;
   if (n0 > 0) accumulate(a.part0, a.f32_0, n0, a.nchunk0, a.C0, c_lo);
   if (n1 > 0) accumulate(a.part1, a.f32_1, n1, a.nchunk1, a.C1, c_lo + n0 - a.C0);
   s = wave_sum(s); q = wave_sum(q);
@@ -142,7 +146,12 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
   if (var < 0) var = 0;
   const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
   const float meanf = (float)mean;
-  for (int c = c_lo + lane; c < c_lo + cpg; c += 64) {
+  if (own) {
+    const float sc = rstd * g_own;
+    a.scale[(size_t)b * C + c_own] = sc;
+    a.shift[(size_t)b * C + c_own] = b_own - meanf * sc;
+  }
+  for (int c = c_lo + lane + 64; c < c_lo + cpg; c += 64) {   // groups wider than a wave (not in the reference configs)
     const float sc = rstd * a.gamma[c];
     a.scale[(size_t)b * C + c] = sc;
     a.shift[(size_t)b * C + c] = a.beta[c] - meanf * sc;
