@@ -29,6 +29,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef DSX_WS_DEPTH_EXPR
+#define DSX_WS_DEPTH_EXPR (bm == 64 ? 5 : (ks == 1 ? 3 : 4))   // measured: one more group in flight than the HBM latency strictly needs
+#endif
 #ifndef DSX_LOADER_PRIO
 #define DSX_LOADER_PRIO 1
 #endif
@@ -1330,7 +1333,7 @@ static constexpr bool ws_tile_ok(int tile) {
 int conv_ws_tile_wm(int tile) { return ws_tile(tile).WM; }
 static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activations in flight beyond the current one
   const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
-  return bm == 64 ? 4 : (ks == 1 ? 2 : 3);
+  return DSX_WS_DEPTH_EXPR;
 }
 static constexpr int kWsLoaderWaves = 4;
 // patch pixels the WS loaders are sized for: one image per tile, square-ish tiles (16x8 / 8x16 -> 18x10,
