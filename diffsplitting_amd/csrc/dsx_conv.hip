@@ -32,6 +32,9 @@
 #ifndef DSX_WS_DEPTH_EXPR
 #define DSX_WS_DEPTH_EXPR (bm == 64 ? 5 : (ks == 1 ? 3 : 4))   // measured: one more group in flight than the HBM latency strictly needs
 #endif
+#ifndef DSX_PF
+#define DSX_PF 2
+#endif
 #ifndef DSX_LOADER_PRIO
 #define DSX_LOADER_PRIO 1
 #endif
@@ -1077,7 +1080,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   ws_barrier();   // image of item 0 is ready
   DSX_STAMP_T(0, tid == 0);
   int g = 0, ti = 0;
-  constexpr int PF = NB == 2 ? 1 : 2;         // operand fragments are read PF steps ahead of their MFMAs (a step is NB x longer)
+  constexpr int PF = NB == 2 ? 1 : DSX_PF;         // operand fragments are read PF steps ahead of their MFMAs (a step is NB x longer)
   static_assert(PF < NSTEP && PF * MB <= 15, "lgkmcnt is 4 bits");
   for (int v = 0; v < total; ++v) {
     unsigned aaddr[MB][KS];                   // LDS byte address of the fragment rows in this item's image
