@@ -208,7 +208,7 @@ __device__ __forceinline__ void store16(void* out, size_t elem, const float (&x)
 // code has no predicates.  LDS image: pixel stride PIXB, row pitch `a.lds_row` chosen by the
 // host so that ds_read_b128 of a 32-row fragment is bank-conflict-free (see conv_lds_row).
 template <typename DT, int MB, int WM, int WN, int KS, int S, int CPG, int D, int MAX_IT>
-__global__ __launch_bounds__(256, (MB == 1 ? 4 : (MB == 2 ? 3 : (MB == 4 ? 2 : 1)))) void k_conv_mfma(const ConvArgs a) {
+__global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (MB == 4 ? 2 : 1)))) void k_conv_mfma(const ConvArgs a) {
   constexpr int KC = Chunk<DT>::KC;
   constexpr int CPU = Unit<DT>::N;            // channels per 16-byte staging unit
   constexpr int ES = (int)sizeof(DT);         // bytes per activation element in HBM
