@@ -704,8 +704,6 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   float* const aff_base = (float*)(lds + 2 * BUFB);
   unsigned char* const raw_base = lds + 2 * BUFB + 2 * AFFB;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;  // LDS byte address of lds[0]
-  const int Hi = a.up ? a.Hs * 2 : a.Hs;
-  const int Wi = a.up ? a.Ws * 2 : a.Ws;
   const int G = a.kchunks / CPG;                // channel groups per tile (no split-K here; host: G >= 2, TB == 1)
 
   // persistent work list: this workgroup owns N tile `nt` and M tiles p, p+wpn, ...
@@ -794,7 +792,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     TilePos posI{p0 % a.tiles_x, (p0 / a.tiles_x) % a.tiles_y, p0 / per_img};   // tile being issued
     TilePos posC = posI;                                                         // tile being consumed
     int baseI = tile_base(posI), flagsI = tile_flags(posI), flagsC = flagsI;
-    int tiI = 0, gI = 0;      // next item to issue
+    int gI = 0;               // group of the next item to issue
     int tiC = 0, gC = 0;      // next item to consume
 
     // DMA the raw patch of item (tiI, gI) into ring slot `slot`; every wave issues exactly NIT instructions
@@ -813,7 +811,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, ldst, 16, vo, 0, 0, 0);
       }
       if (++gI == G) {
-        gI = 0; ++tiI;
+        gI = 0;
         tile_advance(posI);
         baseI = tile_base(posI); flagsI = tile_flags(posI);
       }
@@ -1035,7 +1033,8 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   constexpr int NR = 16 / CPU;   // 16-byte pieces of a lane's 16 residual values
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 addv[NB][4], affv[2];
-  constexpr bool PRE_RESID = NB == 1;   // with two N blocks per wave the residual no longer fits: read in the epilogue
+  constexpr bool PRE_RESID = NB == 1;   // two N blocks per wave: the residual no longer fits (and hipcc rejects the
+                                        // prefetch with NB = 2: 'illegal instruction'): it is read in the epilogue
   uint4 residv[PRE_RESID ? MB : 1][NB][NR];      // storage type; all-zero bits are 0.0 in both
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
