@@ -617,7 +617,8 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   // Pass 0: the warp-specialised persistent kernel only needs ~one workgroup per CU: take the widest
   // tile (least re-staging of the activations per output channel) that still gives >= ws_min work items.
   static const int ws_on = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
-  static const int ws_min = getenv("DSX_WS_MIN_GRID") ? atoi(getenv("DSX_WS_MIN_GRID")) : 224;
+  // (read at every plan, not cached: the parity tests lower it to force the persistent kernel onto small grids)
+  const int ws_min = getenv("DSX_WS_MIN_GRID") ? atoi(getenv("DSX_WS_MIN_GRID")) : 224;
   // the 128 x 128 tile (2 x 2 waves of 64 pixels x 64 channels: each LDS pixel fragment feeds two MFMAs and each
   // converted group twice the MFMA work of the 64 x 128 tile) wherever it still fills the chip
   static const std::vector<int> ws_wide3 = tile_order("DSX_TILES_WS_WIDE", {TILE_128x128, TILE_64x128});

@@ -145,6 +145,17 @@ class UNetEngine:
     def num_launches(self, B, H, W, cond_channels=0):
         return int(lib.dsx_exec_num_launches(self.executor(B, H, W, cond_channels)))
 
+    def op_descriptions(self, B, H, W, cond_channels=0):
+        """Descriptions of the plan's launches in order (dsx_exec_op_info), e.g. 'conv3x3 64->64 @128x128 tile128x64 ws'."""
+        ex = self.executor(B, H, W, cond_channels)
+        desc = C.create_string_buffer(256)
+        kind, fl, by = C.c_int(), C.c_double(), C.c_double()
+        out = []
+        for i in range(int(lib.dsx_exec_num_ops(ex))):
+            check(lib.dsx_exec_op_info(ex, i, desc, 256, C.byref(kind), C.byref(fl), C.byref(by)))
+            out.append(desc.value.decode())
+        return out
+
     def forward(self, x, time=None, cond_channels=0):
         """denoise_fn(x, t): x (B,Cin,H,W) fp32 cuda NCHW -> (B,Cout,H,W)."""
         if not x.is_cuda or x.dtype != torch.float32:

@@ -63,6 +63,47 @@ def test_unet_forward_bf16_psnr(name, dev):
     assert p > 35.0
 
 
+@pytest.mark.parametrize("name", ["sr3_tiny", "hagen_64", "sr3_128"])
+def test_unet_forward_persistent_kernel_forced(name, dev, monkeypatch):
+    """The warp-specialised persistent conv kernel (the one the B = 16 benchmark runs on) forced onto the
+    small test grids (DSX_WS_MIN_GRID=1): fp32 build within 1e-3 of the golden output, bf16 build by PSNR."""
+    monkeypatch.setenv("DSX_WS_MIN_GRID", "1")
+    sd, g = golden_state_dict("unet_" + name)
+    case = cases.UNET_CASES[name]
+    x, t = cases.make_unet_inputs(name)
+    eng = build_engine(case["cfg"], case["flavour"], sd)
+    n_ws = sum("ws" in d.split() for d in eng.op_descriptions(*x.shape[:1], *x.shape[2:]))
+    assert n_ws > 0, "no launch of this plan uses the persistent kernel"
+    y = eng.forward(x.to(dev), t.to(dev).float() if case["flavour"] == "sr3" else t.to(dev)).cpu().numpy()
+    assert maxabs(y, g["y"]) <= FP32_TOL, maxabs(y, g["y"])
+    eng16 = build_engine(case["cfg"], case["flavour"], sd, dtype="bf16")
+    y16 = eng16.forward(x.to(dev), t.to(dev).float() if case["flavour"] == "sr3" else t.to(dev)).cpu().numpy()
+    p = psnr(g["y"], y16)
+    print(f"\n{name}: persistent kernel forced: fp32 max-abs {maxabs(y, g['y']):.3e} ({n_ws} ws launches), bf16 PSNR {p:.1f} dB")
+    assert p > 35.0
+
+
+def test_benchmark_batch_matches_single_image_path(dev):
+    """B = 16 of the headline config runs on the persistent kernels (128x128 / 64x128 / 128x64 tiles), B = 1 on
+    k_conv_mfma: image 0 of the batch must agree with the single-image forward (same bf16 operands, other tiling)."""
+    name = "sr3_128"
+    sd, g = golden_state_dict("unet_" + name)
+    case = cases.UNET_CASES[name]
+    x1, t1 = cases.make_unet_inputs(name)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.cat([x1, torch.randn((15,) + tuple(x1.shape[1:]), generator=gen)])
+    t = torch.cat([t1.float(), 0.05 + 0.95 * torch.rand((15, 1), generator=gen)])
+    eng = build_engine(case["cfg"], case["flavour"], sd, dtype="bf16")
+    n_ws = sum("ws" in d.split() for d in eng.op_descriptions(16, 128, 128))
+    assert n_ws >= 60, n_ws
+    y16 = eng.forward(x.to(dev), t.to(dev)).cpu().numpy()
+    y1 = eng.forward(x1.to(dev), t1.to(dev).float()).cpu().numpy()
+    p = psnr(y1[0], y16[0])
+    print(f"\nB=16 (persistent kernels, {n_ws} ws launches) vs B=1 (k_conv_mfma): PSNR {p:.1f} dB; vs fp32 golden {psnr(g['y'][0], y16[0]):.1f} dB")
+    assert p > 50.0
+    assert psnr(g["y"][0], y16[0]) > 35.0
+
+
 def test_unet_forward_naive_conv_crosscheck(dev, monkeypatch):
     """The plain direct-conv kernel (DSX_CONV_IMPL=naive) and the MFMA kernel agree."""
     monkeypatch.setenv("DSX_CONV_IMPL", "naive")
