@@ -52,9 +52,9 @@ def random_init_state_dict(names, shapes, seed=0):
     return sd
 
 
-def cpu_baseline(sd, batch=4, warm=1, timed=3):
+def cpu_baseline(sd, batch=4, warm=2, timed=40):
     """The CPU oracle (oracle/, a checked restatement of the reference's p_sample)
-    on this host's cores: a bounded sample of `timed` reverse steps at batch 4,
+    on this host's cores: a bounded sample (about 10-15 s) of `timed` reverse steps at batch 4,
     extrapolated to the 2000-step loop (per-step cost is step-independent)."""
     from oracle import samplers
     torch.set_grad_enabled(False)
