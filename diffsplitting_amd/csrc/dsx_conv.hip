@@ -197,6 +197,58 @@ __device__ __forceinline__ void store16(void* out, size_t elem, const float (&x)
   }
 }
 
+// LDS accesses of the loader waves go through inline asm: for a ds_read that may alias an LDS-DMA
+// destination hipcc would insert s_waitcnt vmcnt(0) and drain the whole DMA ring; ordering is done by
+// the counted vmcnt waits (wait_item) instead.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+static __device__ __forceinline__ f32x4_t lds_read_b128_asm(unsigned addr) {
+  f32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+static __device__ __forceinline__ void lds_write_b64_asm(unsigned addr, u32x2_t w) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(w) : "memory");
+}
+static __device__ __forceinline__ void lds_write_b128_asm(unsigned addr, f32x4_t w) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w) : "memory");
+}
+
+static __device__ __forceinline__ void ws_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: own LDS writes visible, DMAs stay in flight
+  __builtin_amdgcn_s_barrier();
+}
+template <int N> static __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0F70);  // vmcnt(N) only
+}
+
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <class F, int... I>
+static __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> static __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// MFMA operand fragments of the compute waves are read with explicit ds_read_b128 + counted lgkmcnt waits,
+// PF steps ahead of their MFMAs: left to itself the register-starved scheduler puts every read right before
+// its use ("ds_read; s_waitcnt lgkmcnt(0); v_mfma"), which exposes the LDS latency on every MFMA.
+template <int OFF> static __device__ __forceinline__ void lds_read_frag(f32x4_t& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a, f32x4_t& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a, f32x4_t& b, f32x4_t& c, f32x4_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+
 // MB   : 32-row M blocks per wave;  WM x WN waves (WM*WN == 4); every wave owns ONE
 //        32-channel N block, so with WM == 1 no weight fragment is loaded twice.
 // CPG  : channel chunks staged per barrier ("group"); 1 for 3x3, 2 for 1x1 (few steps per chunk)
@@ -454,33 +506,55 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
   __syncthreads();
   DSX_STAMP(3);
 
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;  // LDS byte address of lds[0]
+  constexpr int PF = 1;   // operand fragments are read one step ahead of their MFMAs (see lds_read_frag)
   for (int g = g0; g < g1; ++g) {
     const bool more = (g + 1) < g1;
-    const unsigned char* abuf = lds + ((g - g0) & 1) * BUFB;
     const int qbase = g * NSTEP;
 
     if (more) stage_load(g + 1);
     DSX_STAMP(8 + 4 * (g - g0));
 
+    unsigned aaddr[MB][KS];
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      const uint4 bcur = bq[s % D];
-      if (!(a.ablate & 4)) bq[s % D] = load_b(qbase + s + D);
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) aaddr[mb][dy] = lds0 + ((g - g0) & 1) * BUFB + abase[mb][dy];
+    f32x4_t fb[PF + 1][MB];
+    auto read_step = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
       constexpr int kTapSteps = TAPS * 2;
-      const int cg = s / kTapSteps, tap = (s >> 1) % TAPS, fs = s & 1;
-      const int dy = tap / KS, dx = tap % KS;
-      const int imm = dx * PIXB + cg * 64 + fs * 32;   // compile-time after unrolling
-      if (a.ablate & 8) continue;
+      constexpr int cg = s / kTapSteps, tap = (s >> 1) % TAPS, fs = s & 1;
+      constexpr int dy = tap / KS, dx = tap % KS;
+      constexpr int imm = dx * PIXB + cg * 64 + fs * 32;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) lds_read_frag<imm>(fb[s % (PF + 1)][mb], aaddr[mb][dy]);
+    };
+    static_for<PF>(read_step);
+    static_for<NSTEP>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      const uint4 bcur = bq[s % D];
+      bq[s % D] = load_b(qbase + s + D);
+      if constexpr (s + PF < NSTEP) read_step(std::integral_constant<int, s + PF>{});
+      constexpr int ahead = (NSTEP - 1 - s < PF ? NSTEP - 1 - s : PF) * MB;   // younger reads that may stay in flight
+      constexpr int cb = s % (PF + 1);
+      static_assert(PF * MB <= 15, "lgkmcnt is 4 bits");
+      if constexpr (MB == 1) wait_frags<ahead>(fb[cb][0]);
+      else if constexpr (MB == 2) wait_frags<ahead>(fb[cb][0], fb[cb][1]);
+      else if constexpr (MB == 4) wait_frags<ahead>(fb[cb][0], fb[cb][1], fb[cb][2], fb[cb][3]);
+      else {
+        wait_frags<ahead>(fb[cb][0], fb[cb][1], fb[cb][2], fb[cb][3]);   // the wait; the rest only need the ordering
+#pragma unroll
+        for (int mb = 4; mb < MB; ++mb) asm volatile("" : "+v"(fb[cb][mb]));
+      }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const uint4 av = *(const uint4*)(abuf + abase[mb][dy] + imm);
         if constexpr (IS_BF16) {
-          // weights as the A operand, pixels as B: the accumulator then holds, per lane, one pixel's
-          // channels in groups of 4 consecutive -> 16-B epilogue loads/stores
+          // weights as the A operand, pixels as B: the accumulator then holds, per lane, one pixel's channels
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur),
-                                                            __builtin_bit_cast(bf16x8, av), acc[mb], 0, 0, 0);
+                                                            __builtin_bit_cast(bf16x8, fb[cb][mb]), acc[mb], 0, 0, 0);
         } else {
-          const float4 af = __builtin_bit_cast(float4, av);
+          const float4 af = __builtin_bit_cast(float4, fb[cb][mb]);
           const float4 bf = __builtin_bit_cast(float4, bcur);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc[mb], 0, 0, 0);
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc[mb], 0, 0, 0);
@@ -488,7 +562,7 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc[mb], 0, 0, 0);
         }
       }
-    }
+    });
 
     DSX_STAMP(9 + 4 * (g - g0));
     if (more && !(a.ablate & 32)) stage_store(g + 1, (g + 1 - g0) & 1);
@@ -609,57 +683,6 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
 // on across tile boundaries, per-workgroup setup is paid once), and there is one raw s_barrier per
 // group (never __syncthreads: its vmcnt(0) would drain the DMA ring).
 // ===========================================================================================
-// LDS accesses of the loader waves go through inline asm: for a ds_read that may alias an LDS-DMA
-// destination hipcc would insert s_waitcnt vmcnt(0) and drain the whole DMA ring; ordering is done by
-// the counted vmcnt waits (wait_item) instead.
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-static __device__ __forceinline__ f32x4_t lds_read_b128_asm(unsigned addr) {
-  f32x4_t v;
-  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-  return v;
-}
-static __device__ __forceinline__ void lds_write_b64_asm(unsigned addr, u32x2_t w) {
-  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(w) : "memory");
-}
-static __device__ __forceinline__ void lds_write_b128_asm(unsigned addr, f32x4_t w) {
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w) : "memory");
-}
-
-static __device__ __forceinline__ void ws_barrier() {
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: own LDS writes visible, DMAs stay in flight
-  __builtin_amdgcn_s_barrier();
-}
-template <int N> static __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
-  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0F70);  // vmcnt(N) only
-}
-
-
-// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
-template <class F, int... I>
-static __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F> static __device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-// MFMA operand fragments of the compute waves are read with explicit ds_read_b128 + counted lgkmcnt waits,
-// PF steps ahead of their MFMAs: left to itself the register-starved scheduler puts every read right before
-// its use ("ds_read; s_waitcnt lgkmcnt(0); v_mfma"), which exposes the LDS latency on every MFMA.
-template <int OFF> static __device__ __forceinline__ void lds_read_frag(f32x4_t& d, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
-}
-template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a, f32x4_t& b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
-}
-template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a, f32x4_t& b, f32x4_t& c, f32x4_t& d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
-
 template <typename DT, int MB, int WM, int WN, int NB, int KS, int CPG, int D, int NIT, int P, int LW>
 __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) {
   constexpr int LT = 64 * LW;                   // loader threads
