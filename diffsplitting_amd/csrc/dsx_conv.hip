@@ -739,7 +739,9 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     const int bid = blockIdx.x, xcd = bid & 7, k = bid >> 3, NT = a.n_tiles;
     if (NT <= 8 && (8 % NT) == 0 && (wpn % (8 / NT)) == 0) {
       nt = xcd % NT;
-      p0 = k * (8 / NT) + xcd / NT;
+      // each XCD owns a contiguous band of M tiles (neighbouring tiles share halo rows in its L2) ...
+      if (a.xcd_bands) p0 = (xcd / NT) * (wpn / (8 / NT)) + k;
+      else p0 = k * (8 / NT) + xcd / NT;         // ... or tiles dealt round-robin (DSX_XCD_BANDS=0)
     } else if ((NT & 7) == 0) {
       const int per = NT >> 3;
       nt = xcd + 8 * (k % per);

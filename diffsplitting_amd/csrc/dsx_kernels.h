@@ -44,6 +44,7 @@ struct ConvArgs {
   int tiles_x, tiles_y, m_tiles, n_tiles;
   int lds_row;            // LDS bytes per patch row (conv_lds_row)
   int ws_wg_per_n;        // warp-specialised kernel: persistent workgroups per N tile (0: k_conv_mfma)
+  int xcd_bands;          // k_conv_ws: an XCD's workgroups take a contiguous band of M tiles (else round-robin)
   float* stat_part;       // fused GroupNorm partials [B][tiles_x*tiles_y*WM][Cout][2] (fp32) or nullptr
   unsigned long long* stamp;  // diagnostic s_memtime stamps of workgroup `stamp_block` (or nullptr)
   int stamp_block;

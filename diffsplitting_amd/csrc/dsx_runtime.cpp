@@ -774,6 +774,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
              [=](hipStream_t st) { return launch_splitk_reduce(ra, st); });
     } else {
       ConvArgs w = a;
+      w.xcd_bands = getenv("DSX_XCD_BANDS") ? atoi(getenv("DSX_XCD_BANDS")) : 1;
       w.ws_wg_per_n = std::min(a.m_tiles, std::max(1, 256 / std::max(1, a.n_tiles)));
       if (a.n_tiles <= 8 && 8 % a.n_tiles == 0) {   // whole XCD groups per N tile (see k_conv_ws)
         const int unit = 8 / a.n_tiles;
