@@ -721,11 +721,11 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   const int PP = PPI << a.tb_log2;
   const int RB = a.lds_row;
   const int BUFB = (PH << a.tb_log2) * RB;
-  // [image 0][image 1][GroupNorm scale/shift of two tiles' images][raw ring]
+  // [image 0][image 1][GroupNorm scale/shift of three tiles' images][raw ring]
   const int C = a.C0 + a.C1;
   const int AFFB = a.has_gn ? ((2 * C * 4 + 15) & ~15) : 0;     // bytes of one tile's {scale[C], shift[C]}
   float* const aff_base = (float*)(lds + 2 * BUFB);
-  unsigned char* const raw_base = lds + 2 * BUFB + 2 * AFFB;
+  unsigned char* const raw_base = lds + 2 * BUFB + 3 * AFFB;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;  // LDS byte address of lds[0]
   const int G = a.kchunks / CPG;                // channel groups per tile (no split-K here; host: G >= 2, TB == 1)
 
@@ -818,7 +818,9 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     TilePos posC = posI;                                                         // tile being consumed
     int baseI = tile_base(posI), flagsI = tile_flags(posI), flagsC = flagsI;
     int gI = 0;               // group of the next item to issue
-    int tiC = 0, gC = 0;      // next item to consume
+    [[maybe_unused]] int tiC = 0;   // tile of the next item to consume (diagnostic stamps only)
+    int gC = 0;               // its group
+    int affslot = 0;          // tiC % 3: LDS slot of that tile's scale/shift
 
     // DMA the raw patch of item (tiI, gI) into ring slot `slot`; every wave issues exactly NIT instructions
     auto issue = [&](int slot) {
@@ -855,9 +857,9 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       cF = gC * (CPG * KC) + cvg * CPU;
       flagsF = flagsC;
       gnF = a.gn_scale != nullptr && cF < C;
-      const unsigned src = lds0 + 2 * BUFB + 2 * AFFB + slot * RAWB + ltid * 16;
+      const unsigned src = lds0 + 2 * BUFB + 3 * AFFB + slot * RAWB + ltid * 16;
       if (gnF) {
-        const unsigned af = lds0 + 2 * BUFB + (tiC & 1) * AFFB;
+        const unsigned af = lds0 + 2 * BUFB + affslot * AFFB;   // slot tiC % 3
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
           asm volatile("ds_read_b128 %0, %1" : "=v"(av[q]) : "v"(af + (cF + 4 * q) * 4) : "memory");
@@ -869,6 +871,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         asm volatile("ds_read_b128 %0, %1" : "=v"(rv[it]) : "v"(src + it * (LT * 16)) : "memory");
       if (++gC == G) {
         gC = 0; ++tiC;
+        if (++affslot == 3) affslot = 0;
         tile_advance(posC);
         flagsC = tile_flags(posC);
       }
@@ -1046,8 +1049,15 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     *(float4*)(dst + tid * 4) = *(const float4*)(a.gn_scale + (size_t)b * C + tid * 4);
     *(float4*)(dst + C + tid * 4) = *(const float4*)(a.gn_shift + (size_t)b * C + tid * 4);
   };
+  // Three slots (tile % 3).  The scale/shift of tile t is written by the epilogue of tile t-3, i.e. it is visible
+  // after the barrier that ends item (t-2)*G, and the loaders first read it when they fetch item t*G, after the
+  // barrier that ends item t*G - 3: safe for every G >= 2.  (With two slots and a lead of two tiles the fetch of a
+  // G = 2 layer raced with the epilogue that writes the slot.)
+  TilePos n3 = nn;         // tile ti + 3
+  tile_advance(n3);
   load_aff(cur.b, 0);
   if (ntile > 1) load_aff(nxt.b, 1);
+  if (ntile > 2) load_aff(nn.b, 2);
 
   // Epilogue operands live in registers and are fetched one tile ahead, at the start of the previous tile's
   // epilogue (right after its own operands were consumed): the loads then have the rest of that epilogue
@@ -1073,7 +1083,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #pragma unroll
       for (int q = 0; q < NR; ++q) residv[mb][nb][q] = make_uint4(0u, 0u, 0u, 0u);
   affv[0] = affv[1] = zero4;
-  // t: the tile whose epilogue will use the operands; b_aff: image of the tile two after it
+  // t: the tile whose epilogue will use the operands; b_aff: image of the tile three after it
   auto prefetch_epilogue = [&](const TilePos& t, bool want_aff, int b_aff) {
     if (a.film) {
 #pragma unroll
@@ -1098,12 +1108,12 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       affv[1] = *(const float4*)(a.gn_shift + (size_t)b_aff * C + tid * 4);
     }
   };
-  prefetch_epilogue(cur, ntile > 2, nn.b);
+  prefetch_epilogue(cur, ntile > 3, n3.b);
 
   ws_barrier();   // scale/shift visible to the loaders
   ws_barrier();   // image of item 0 is ready
   DSX_STAMP_T(0, tid == 0);
-  int g = 0, ti = 0;
+  int g = 0, ti = 0, aslot = 0;   // aslot == ti % 3
   constexpr int PF = NB == 2 ? 1 : DSX_PF;         // operand fragments are read PF steps ahead of their MFMAs (a step is NB x longer)
   static_assert(PF < NSTEP && PF * MB <= 15, "lgkmcnt is 4 bits");
   for (int v = 0; v < total; ++v) {
@@ -1161,9 +1171,9 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 
     // ---- tile finished: epilogue (+ fused statistics).  Accumulator register r of a lane is channel
     //      16 * lh + r of the wave's 32-channel block, for the lane's pixel (see store16).
-    // scale/shift of tile ti+2 -> LDS (tile ti+1's is already there; slot parity of ti+2 == ti, whose use has ended)
-    if (a.gn_scale != nullptr && ti + 2 < ntile && tid * 4 < C) {
-      float* dst = aff_base + (size_t)(ti & 1) * (AFFB / 4);
+    // scale/shift of tile ti+3 -> LDS slot (ti+3) % 3 == ti % 3, whose use ended with tile ti
+    if (a.gn_scale != nullptr && ti + 3 < ntile && tid * 4 < C) {
+      float* dst = aff_base + (size_t)aslot * (AFFB / 4);
       *(float4*)(dst + tid * 4) = affv[0];
       *(float4*)(dst + C + tid * 4) = affv[1];
     }
@@ -1194,11 +1204,12 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         }
       }
     DSX_STAMP_T(61, tid == 0 && ti == 1);
-    // the operand registers are free again: fetch the next tile's (and the scale/shift of tile ti+3)
+    // the operand registers are free again: fetch the next tile's (and the scale/shift of the tile three after it)
     const TilePos done = cur;
     ++ti;
-    cur = nxt; nxt = nn; tile_advance(nn);
-    if (ti < ntile) prefetch_epilogue(cur, ti + 2 < ntile, nn.b);
+    if (++aslot == 3) aslot = 0;
+    cur = nxt; nxt = nn; nn = n3; tile_advance(n3);
+    if (ti < ntile) prefetch_epilogue(cur, ti + 3 < ntile, n3.b);
 
     const int o0 = tile_pixel0(done) * a.out_ld;
 #pragma unroll
@@ -1384,7 +1395,7 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   const size_t bufb = (size_t)(ph << a.tb_log2) * a.lds_row;
   const size_t rawb = (size_t)ws_nit(dtype, tile, ks) * (kWsLoaderWaves * 64 * 16);
   const size_t affb = a.has_gn ? (((size_t)2 * (a.C0 + a.C1) * 4 + 15) & ~(size_t)15) : 0;  // never keyed on a pointer
-  const size_t total = 2 * bufb + 2 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb;
+  const size_t total = 2 * bufb + 3 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb;
   if (a.tb_log2 != 0 || a.kchunks / conv_cpg(ks) < 2) return 0;   // one image per tile, >= 2 channel groups
   // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
   if ((long long)a.B * a.Ho * a.Wo * std::max(a.out_ld, a.resid_ld) >= (1LL << 31)) return 0;   // 32-bit element offsets
