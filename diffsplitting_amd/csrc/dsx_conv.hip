@@ -32,6 +32,12 @@
 #ifndef DSX_WS_DEPTH_EXPR
 #define DSX_WS_DEPTH_EXPR (bm == 64 ? 5 : (ks == 1 ? 3 : 4))   // measured: one more group in flight than the HBM latency strictly needs
 #endif
+// residual prefetch one tile ahead: only with one N block per wave.  With two, the register demand passes 256 and
+// hipcc (ROCm 7.2) fails in its spill path ("Illegal instruction detected: Operand has incorrect register class
+// V_CMP_NE_U32_e32 0, $src_private_base"); the same happens for a 64 x 256 tile (MB 2, WM 1, WN 4, NB 2).
+#ifndef DSX_PRE_RESID_EXPR
+#define DSX_PRE_RESID_EXPR (NB == 1)
+#endif
 #ifndef DSX_PF
 #define DSX_PF 2
 #endif
@@ -767,20 +773,20 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     struct TilePos { int tx, ty, b; };
     const int per_img = a.tiles_x * a.tiles_y;
     const int adv_x = wpn % a.tiles_x, adv_y = (wpn / a.tiles_x) % a.tiles_y, adv_b = wpn / per_img;
-    auto tile_advance = [&](TilePos& t) {
+    auto tile_advance = [&](TilePos& t) __attribute__((always_inline)) {
       t.tx += adv_x;
       if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; t.ty += 1; }
       t.ty += adv_y;
       if (t.ty >= a.tiles_y) { t.ty -= a.tiles_y; t.b += 1; }
       t.b += adv_b;
     };
-    auto tile_flags = [&](const TilePos& t) -> int {   // bit0 top, bit1 bottom, bit2 left, bit3 right
+    auto tile_flags = [&](const TilePos& t) __attribute__((always_inline)) -> int {   // bit0 top, bit1 bottom, bit2 left, bit3 right
       return (PAD == 0) ? 0
                         : ((t.ty == 0 ? 1 : 0) | (t.ty == a.tiles_y - 1 ? 2 : 0) | (t.tx == 0 ? 4 : 0) |
                            (t.tx == a.tiles_x - 1 ? 8 : 0));
     };
     // source pixel index of the patch origin's *output* pixel (oy0, ox0); `rel` is added to it
-    auto tile_base = [&](const TilePos& t) -> int {
+    auto tile_base = [&](const TilePos& t) __attribute__((always_inline)) -> int {
       const int oy0 = t.ty << a.th_log2, ox0 = t.tx << a.tw_log2;   // even whenever a.up (TW, TH >= 2)
       return (t.b * a.Hs + (a.up ? oy0 >> 1 : oy0)) * a.Ws + (a.up ? ox0 >> 1 : ox0);
     };
@@ -823,7 +829,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     int affslot = 0;          // tiC % 3: LDS slot of that tile's scale/shift
 
     // DMA the raw patch of item (tiI, gI) into ring slot `slot`; every wave issues exactly NIT instructions
-    auto issue = [&](int slot) {
+    auto issue = [&](int slot) __attribute__((always_inline)) {
       const int c = gI * (CPG * KC) + cvg * CPU;
       const bool first = gI * (CPG * KC) < a.C0;            // uniform: a group never straddles the sources
       const int cs = first ? a.C0 : a.C1;
@@ -853,7 +859,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     bool gnF = false;
     // fetch: scale/shift (parked in LDS by the compute waves -- an ordinary global load here would make the
     // compiler wait vmcnt(0) and drain the DMA ring) and the raw units of item (tiC, gC); advances (tiC, gC)
-    auto fetch = [&](int slot) {
+    auto fetch = [&](int slot) __attribute__((always_inline)) {
       cF = gC * (CPG * KC) + cvg * CPU;
       flagsF = flagsC;
       gnF = a.gn_scale != nullptr && cF < C;
@@ -876,7 +882,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         flagsC = tile_flags(posC);
       }
     };
-    auto convert = [&](int buf) {
+    auto convert = [&](int buf) __attribute__((always_inline)) {
       const unsigned dst = lds0 + buf * BUFB;
       // the wait, then empty volatile asms that every read's result passes through: volatile asms keep their
       // order, so no use of a result can be scheduled above the wait
@@ -918,7 +924,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       DSX_STAMP_T(123, tid == 256 && tiC == 2 && gC == 0);
     };
     // wait until the DMAs of the item to fetch have landed; `young` = younger items that may stay in flight
-    auto wait_young = [&](int young) {
+    auto wait_young = [&](int young) __attribute__((always_inline)) {
       if (young >= P) wait_vmcnt<P * NIT>();
       else if (P > 1 && young == P - 1) wait_vmcnt<(P > 1 ? (P - 1) * NIT : 0)>();
       else if (P > 2 && young == P - 2) wait_vmcnt<(P > 2 ? (P - 2) * NIT : 0)>();
@@ -928,12 +934,12 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     };
 
     int issued = 0, slotI = 0, slotF = 0;   // items issued; ring slot of the next issue / next fetch
-    auto issue_next = [&]() {
+    auto issue_next = [&]() __attribute__((always_inline)) {
       issue(slotI);
       ++issued;
       if (++slotI == NSLOT) slotI = 0;
     };
-    auto fetch_next = [&]() {
+    auto fetch_next = [&]() __attribute__((always_inline)) {
       fetch(slotF);
       if (++slotF == NSLOT) slotF = 0;
     };
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   const int qtot = G * NSTEP;                   // the stream restarts at every tile (same N blocks)
   int qn = 0;                                   // next step to prefetch (wraps)
   struct WFrag { uint4 v[NB]; };                // one step's weight fragments (by value: stays in registers)
-  auto load_b = [&]() -> WFrag {
+  auto load_b = [&]() __attribute__((always_inline)) -> WFrag {
     WFrag f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   struct TilePos { int tx, ty, b; };
   const int per_img = a.tiles_x * a.tiles_y;
   const int adv_x = wpn % a.tiles_x, adv_y = (wpn / a.tiles_x) % a.tiles_y, adv_b = wpn / per_img;
-  auto tile_advance = [&](TilePos& t) {
+  auto tile_advance = [&](TilePos& t) __attribute__((always_inline)) {
     t.tx += adv_x;
     if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; t.ty += 1; }
     t.ty += adv_y;
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     orow[mb] = pix * a.out_ld + nbase;
     rrow[mb] = pix * a.resid_ld + nbase;
   }
-  auto tile_pixel0 = [&](const TilePos& t) -> int {   // first output pixel of tile t (uniform)
+  auto tile_pixel0 = [&](const TilePos& t) __attribute__((always_inline)) -> int {   // first output pixel of tile t (uniform)
     return (t.b * a.Ho + (t.ty << a.th_log2)) * a.Wo + (t.tx << a.tw_log2);
   };
   TilePos cur{p0 % a.tiles_x, (p0 / a.tiles_x) % a.tiles_y, p0 / per_img};   // tile ti (being multiplied)
@@ -1043,7 +1049,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   tile_advance(nn);
 
   // GroupNorm scale/shift of image b -> LDS parity slot, for the loader waves (host: C <= 1024)
-  auto load_aff = [&](int b, int slot) {
+  auto load_aff = [&](int b, int slot) __attribute__((always_inline)) {
     if (a.gn_scale == nullptr || tid * 4 >= C) return;
     float* dst = aff_base + (size_t)slot * (AFFB / 4);
     *(float4*)(dst + tid * 4) = *(const float4*)(a.gn_scale + (size_t)b * C + tid * 4);
@@ -1068,8 +1074,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   constexpr int NR = 16 / CPU;   // 16-byte pieces of a lane's 16 residual values
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 addv[NB][4], affv[2];
-  constexpr bool PRE_RESID = NB == 1;   // two N blocks per wave: the residual no longer fits (and hipcc rejects the
-                                        // prefetch with NB = 2: 'illegal instruction'): it is read in the epilogue
+  constexpr bool PRE_RESID = DSX_PRE_RESID_EXPR;   // else the residual is read in the epilogue
   uint4 residv[PRE_RESID ? MB : 1][NB][NR];      // storage type; all-zero bits are 0.0 in both
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
@@ -1084,7 +1089,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       for (int q = 0; q < NR; ++q) residv[mb][nb][q] = make_uint4(0u, 0u, 0u, 0u);
   affv[0] = affv[1] = zero4;
   // t: the tile whose epilogue will use the operands; b_aff: image of the tile three after it
-  auto prefetch_epilogue = [&](const TilePos& t, bool want_aff, int b_aff) {
+  auto prefetch_epilogue = [&](const TilePos& t, bool want_aff, int b_aff) __attribute__((always_inline)) {
     if (a.film) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -1123,7 +1128,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #pragma unroll
       for (int dy = 0; dy < KS; ++dy) aaddr[mb][dy] = lds0 + (v & 1) * BUFB + abase[mb][dy];
     f32x4_t fb[PF + 1][MB];
-    auto read_step = [&](auto sc) {
+    auto read_step = [&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
       constexpr int kTapSteps = TAPS * 2;
       constexpr int cg = s / kTapSteps, tap = (s >> 1) % TAPS, fs = s & 1;
