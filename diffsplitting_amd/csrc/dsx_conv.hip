@@ -60,24 +60,10 @@ __device__ __forceinline__ float swish_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
-// sum over the 16 lanes of a DPP row; every lane of the row ends up with the total
-__device__ __forceinline__ float row16_sum(float v) {
-  int x;
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, x);
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, x);
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false);  // row_ror:4
-  v += __builtin_bit_cast(float, x);
-  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false);  // row_ror:8
-  v += __builtin_bit_cast(float, x);
-  return v;
-}
-
 // 16 per-lane registers -> one total per lane: lane i of a DPP row ends up with the row's sum of register
 // r = 8*bit0(i) + 4*bit1(i) + 2*bit2(i) + bit3(i).  Each butterfly stage halves the register count (the
 // lane keeps the half its bit selects and receives the partner's copy of that half): 15 adds instead of
-// the 64 of sixteen row16_sum calls.
+// the 64 of sixteen full 16-lane reductions.
 template <int CTRL, int BANKS>
 __device__ __forceinline__ float dpp_take(float old, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
@@ -205,17 +191,8 @@ __device__ __forceinline__ void store16(void* out, size_t elem, const float (&x)
 
 // LDS accesses of the loader waves go through inline asm: for a ds_read that may alias an LDS-DMA
 // destination hipcc would insert s_waitcnt vmcnt(0) and drain the whole DMA ring; ordering is done by
-// the counted vmcnt waits (wait_item) instead.
+// the counted vmcnt waits (wait_young) instead.
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-static __device__ __forceinline__ f32x4_t lds_read_b128_asm(unsigned addr) {
-  f32x4_t v;
-  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-  return v;
-}
-static __device__ __forceinline__ void lds_write_b64_asm(unsigned addr, u32x2_t w) {
-  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(w) : "memory");
-}
 static __device__ __forceinline__ void lds_write_b128_asm(unsigned addr, f32x4_t w) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w) : "memory");
 }
