@@ -881,21 +881,21 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         if (loff[it] >= 0) {
           float v[CPU];
           Unit<DT>::unpack(__builtin_bit_cast(uint4, rv[it]), v);
-          if ((edge[it] & flagsF) == 0 && cF < C) {   // padding pixels stay exactly 0 (padded AFTER the activation)
-            if (gnF) {
+          // the arithmetic runs in every lane; padding pixels (and channels past C) are forced to exactly 0
+          // afterwards with one mask per packed register (padded AFTER the activation, as the reference does)
+          if (gnF) {
 #pragma unroll
-              for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
-            }
-            if (a.swish) {
+            for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
+          }
+          if (a.swish) {
 #pragma unroll
-              for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < CPU; ++j) v[j] = 0.f;
+            for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
           }
           if (it == NIT - 1) { asm volatile("" :: "v"(v[0]), "v"(v[CPU - 1])); DSX_STAMP_T(122, tid == 256 && tiC == 2 && gC == 0); }
-          lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, Unit<DT>::pack(v)));
+          uint4 w = Unit<DT>::pack(v);
+          const unsigned keep = ((edge[it] & flagsF) == 0 && cF < C) ? 0xffffffffu : 0u;
+          w.x &= keep; w.y &= keep; w.z &= keep; w.w &= keep;
+          lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, w));
         }
       }
       DSX_STAMP_T(123, tid == 256 && tiC == 2 && gC == 0);
