@@ -29,7 +29,7 @@ class StepTable(C.Structure):
 
 
 FLAVOUR_SR3, FLAVOUR_DDPM = 0, 1
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 TILING_TRIM, TILING_PAD, TILING_SHIFT = 0, 1, 2
 
 _vp, _i, _i64, _u64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
@@ -51,6 +51,8 @@ SIGNATURES = {
     "dsx_exec_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
     "dsx_exec_destroy": (None, [_vp]),
     "dsx_exec_workspace_bytes": (C.c_size_t, [_vp]),
+    "dsx_plan_dry_run": (_i, [C.POINTER(UnetCfg), _i, _i, _i, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                              C.POINTER(_i)]),
     "dsx_exec_num_launches": (_i, [_vp]),
     "dsx_exec_num_ops": (_i, [_vp]),
     "dsx_exec_op_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -48,9 +48,18 @@
 #define DSX_RING_DEPTH 6  // weight-fragment prefetch ring depth for 3x3 (divides 18)
 #endif
 
+// DSX_ABLATE (phase-skipping timing experiments, results wrong) exists only in the diagnostic build
+// (DSX_EXTRA_FLAGS=-DDSX_DIAG ./build.sh); the product binary has no such switch.
+#ifdef DSX_DIAG
+#define DSX_ABLATED(bit) ((a.ablate & (bit)) != 0)
+#else
+#define DSX_ABLATED(bit) false
+#endif
+
 namespace dsx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 
@@ -96,6 +105,12 @@ __device__ __forceinline__ int row16_fold_reg(int lane) {
   return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
 }
 
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+  const _Float16 l = (_Float16)lo, h = (_Float16)hi;  // RNE (v_cvt_f16_f32)
+  return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+}
+__device__ __forceinline__ float f16_lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float f16_hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   __bf16 l = (__bf16)lo, h = (__bf16)hi;  // RNE (v_cvt_pk_bf16_f32)
   unsigned short ls = __builtin_bit_cast(unsigned short, l);
@@ -125,6 +140,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 template <typename DT> struct Chunk;
 template <> struct Chunk<float> { static constexpr int KC = 16; };
 template <> struct Chunk<__bf16> { static constexpr int KC = 32; };
+template <> struct Chunk<_Float16> { static constexpr int KC = 32; };
+// storage kind of an activation tensor as the host passes it (ConvArgs::act_bf16 / out_bf16): 0 fp32, 1 bf16, 2 fp16
+template <typename DT> struct Kind;
+template <> struct Kind<float> { static constexpr int value = 0; };
+template <> struct Kind<__bf16> { static constexpr int value = 1; };
+template <> struct Kind<_Float16> { static constexpr int value = 2; };
 
 // Activations live in HBM in the MFMA operand type (fp32 or bf16); everything is staged in 16-byte units:
 // Unit<DT>::N consecutive channels of one pixel (4 fp32 / 8 bf16), which is also 16 bytes of the LDS image.
@@ -153,15 +174,32 @@ template <> struct Unit<__bf16> {
                       pack_bf16x2(v[6], v[7]));
   }
 };
+template <> struct Unit<_Float16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void unpack(const uint4 r, float (&v)[8]) {
+    v[0] = f16_lo(r.x); v[1] = f16_hi(r.x); v[2] = f16_lo(r.y); v[3] = f16_hi(r.y);
+    v[4] = f16_lo(r.z); v[5] = f16_hi(r.z); v[6] = f16_lo(r.w); v[7] = f16_hi(r.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float (&v)[8]) {
+    return make_uint4(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7]));
+  }
+};
 // one activation element -> float (scalar fallback paths)
 template <typename DT> __device__ __forceinline__ float act_load(const void* p, size_t i) {
-  if constexpr (sizeof(DT) == 2) return __builtin_bit_cast(float, (unsigned)((const unsigned short*)p)[i] << 16);
+  if constexpr (Kind<DT>::value == 1) return __builtin_bit_cast(float, (unsigned)((const unsigned short*)p)[i] << 16);
+  else if constexpr (Kind<DT>::value == 2) return (float)((const _Float16*)p)[i];
   else return ((const float*)p)[i];
 }
-__device__ __forceinline__ void act_store(void* p, size_t i, float v, bool bf16) {
-  if (bf16) {
+__device__ __forceinline__ float act_load_kind(const void* p, size_t i, int kind) {
+  return kind == 1 ? act_load<__bf16>(p, i) : (kind == 2 ? act_load<_Float16>(p, i) : act_load<float>(p, i));
+}
+// kind: 0 fp32, 1 bf16, 2 fp16
+__device__ __forceinline__ void act_store(void* p, size_t i, float v, int kind) {
+  if (kind == 1) {
     const __bf16 h = (__bf16)v;
     ((unsigned short*)p)[i] = __builtin_bit_cast(unsigned short, h);
+  } else if (kind == 2) {
+    ((_Float16*)p)[i] = (_Float16)v;
   } else {
     ((float*)p)[i] = v;
   }
@@ -171,12 +209,16 @@ __device__ __forceinline__ void act_store(void* p, size_t i, float v, bool bf16)
 // holds channel 16*lh + r of the wave's 32-channel block -> 16 consecutive channels per lane.
 // x[16] -> out (+ optional 16-B vector stores); `n0` = first channel, `valid` = channels that exist
 template <bool VEC>
-__device__ __forceinline__ void store16(void* out, size_t elem, const float (&x)[16], bool bf16, int valid) {
+__device__ __forceinline__ void store16(void* out, size_t elem, const float (&x)[16], int kind, int valid) {
   if (VEC) {
-    if (bf16) {
+    if (kind == 1) {
       uint4* q = (uint4*)((unsigned short*)out + elem);
       q[0] = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
       q[1] = make_uint4(pack_bf16x2(x[8], x[9]), pack_bf16x2(x[10], x[11]), pack_bf16x2(x[12], x[13]), pack_bf16x2(x[14], x[15]));
+    } else if (kind == 2) {
+      uint4* q = (uint4*)((unsigned short*)out + elem);
+      q[0] = make_uint4(pack_f16x2(x[0], x[1]), pack_f16x2(x[2], x[3]), pack_f16x2(x[4], x[5]), pack_f16x2(x[6], x[7]));
+      q[1] = make_uint4(pack_f16x2(x[8], x[9]), pack_f16x2(x[10], x[11]), pack_f16x2(x[12], x[13]), pack_f16x2(x[14], x[15]));
     } else {
       float4* q = (float4*)((float*)out + elem);
 #pragma unroll
@@ -185,7 +227,7 @@ __device__ __forceinline__ void store16(void* out, size_t elem, const float (&x)
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      if (r < valid) act_store(out, elem + r, x[r], bf16);
+      if (r < valid) act_store(out, elem + r, x[r], kind);
   }
 }
 
@@ -231,6 +273,23 @@ template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a, f
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 
+
+// one 16-byte fragment pair on the matrix core in the operand type DT (weights = A, pixels = B)
+template <typename DT>
+__device__ __forceinline__ f32x16 mfma_step(const uint4 w, const f32x4_t px, f32x16 acc) {
+  if constexpr (Kind<DT>::value == 1) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, px), acc, 0, 0, 0);
+  } else if constexpr (Kind<DT>::value == 2) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, px), acc, 0, 0, 0);
+  } else {
+    const float4 af = __builtin_bit_cast(float4, px);
+    const float4 bf = __builtin_bit_cast(float4, w);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af.z, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc, 0, 0, 0);
+  }
+}
 
 // MB   : 32-row M blocks per wave;  WM x WN waves (WM*WN == 4); every wave owns ONE
 //        32-channel N block, so with WM == 1 no weight fragment is loaded twice.
@@ -376,7 +435,9 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
   // issue the global loads of group g into registers
   auto stage_load = [&](int g) {
     const int c = g * (CPG * KC) + cvg * CPU;
-    if (a.ablate & 2) return;   // timing experiments only (DSX_ABLATE): skip activation loads
+#ifdef DSX_DIAG
+    if (a.ablate & 2) return;   // timing experiments only (DSX_ABLATE, diagnostic build): skip activation loads
+#endif
     if (a.stage_mode == 0) {
       // fast path (both channel counts multiples of the group width): the whole workgroup reads ONE
       // source in this group -> wave-uniform descriptor, offsets by the memory pipeline, OOB -> 0
@@ -460,7 +521,7 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
       if (loff[it] >= 0) {
         float v[CPU];
         Unit<DT>::unpack(stg[it], v);
-        if (soff[it] >= 0 && c < C && !(a.ablate & 1)) {   // padding pixels stay exactly 0 (padded AFTER the activation)
+        if (soff[it] >= 0 && c < C && !DSX_ABLATED(1)) {   // padding pixels stay exactly 0 (padded AFTER the activation)
           if (has_gn) {
             if (multi_img) load_affine(simg[it]);
 #pragma unroll
@@ -532,23 +593,13 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        if constexpr (IS_BF16) {
-          // weights as the A operand, pixels as B: the accumulator then holds, per lane, one pixel's channels
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur),
-                                                            __builtin_bit_cast(bf16x8, fb[cb][mb]), acc[mb], 0, 0, 0);
-        } else {
-          const float4 af = __builtin_bit_cast(float4, fb[cb][mb]);
-          const float4 bf = __builtin_bit_cast(float4, bcur);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af.z, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc[mb], 0, 0, 0);
-        }
+        // weights as the A operand, pixels as B: the accumulator then holds, per lane, one pixel's channels
+        acc[mb] = mfma_step<DT>(bcur, fb[cb][mb], acc[mb]);
       }
     });
 
     DSX_STAMP(9 + 4 * (g - g0));
-    if (more && !(a.ablate & 32)) stage_store(g + 1, (g + 1 - g0) & 1);
+    if (more && !DSX_ABLATED(32)) stage_store(g + 1, (g + 1 - g0) & 1);
     DSX_STAMP(10 + 4 * (g - g0));
     __syncthreads();
     DSX_STAMP(11 + 4 * (g - g0));
@@ -560,10 +611,11 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
   // permuted): 16 consecutive channels per lane -> 16-byte bias / FiLM / residual loads and NHWC stores.
   // Split-K slices write raw partial sums to their fp32 slab.  The GroupNorm statistics of the tensor being
   // written (sum, sum of squares per channel over this wave's pixels) are accumulated in the same pass.
-  if (a.ablate & 16) return;
+  if (DSX_ABLATED(16)) return;
   const int nbase = (nt * WN + wn) * 32 + 16 * lh;
   const bool partial = a.ksplit > 1;
-  const bool obf = IS_BF16 && a.out_bf16;
+  const int okind = (IS_BF16 && a.out_bf16) ? Kind<DT>::value : 0;   // storage kind of `out`
+  const bool obf = okind != 0;
   void* outp = partial ? (void*)((float*)a.out + (size_t)split * a.slab_stride) : a.out;
   const int oal = obf ? 7 : 3, ral = IS_BF16 ? 7 : 3;   // 16-byte alignment of rows, in elements
   const bool vec = (a.Cout & 15) == 0 && (a.out_ld & oal) == 0 && (!a.resid || (a.resid_ld & ral) == 0);
@@ -609,7 +661,7 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
           }
         }
       }
-      store16<true>(outp, opix * a.out_ld + nbase, x, obf, 16);
+      store16<true>(outp, opix * a.out_ld + nbase, x, okind, 16);
       if (do_stats) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s1[r] += x[r]; s2[r] += x[r] * x[r]; }
@@ -625,7 +677,7 @@ __global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (
           if (a.resid) x[r] += act_load<DT>(a.resid, opix * a.resid_ld + nbase + r);
         }
       }
-      store16<false>(outp, opix * a.out_ld + nbase, x, obf, valid);
+      store16<false>(outp, opix * a.out_ld + nbase, x, okind, valid);
     }
   }
   DSX_STAMP(5);
@@ -681,7 +733,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   constexpr int TAPS = KS * KS;
   constexpr int PAD = KS / 2;
   constexpr int NSTEP = CPG * TAPS * 2;
-  constexpr bool IS_BF16 = sizeof(DT) == 2;
+  [[maybe_unused]] constexpr bool IS_BF16 = sizeof(DT) == 2;
   constexpr int RAWB = NIT * LT * 16;           // one raw ring slot
   constexpr int NSLOT = P + 1;
   static_assert(NSTEP % D == 0, "ring depth must divide the steps per group");
@@ -1132,17 +1184,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          if constexpr (IS_BF16) {
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur.v[nb]),
-                                                                  __builtin_bit_cast(bf16x8, fb[cb][mb]), acc[mb][nb], 0, 0, 0);
-          } else {
-            const float4 af = __builtin_bit_cast(float4, fb[cb][mb]);
-            const float4 bf = __builtin_bit_cast(float4, bcur.v[nb]);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af.z, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc[mb][nb], 0, 0, 0);
-          }
+          acc[mb][nb] = mfma_step<DT>(bcur.v[nb], fb[cb][mb], acc[mb][nb]);
         }
     });
     DSX_STAMP_T(1 + 3 * v, tid == 0 && v < 20);
@@ -1204,7 +1246,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         float x[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = acc[mb][nb][r];
-        store16<true>(a.out, (size_t)(o0 + orow[mb] + 32 * nb), x, IS_BF16, 16);   // host: out is in the storage type
+        store16<true>(a.out, (size_t)(o0 + orow[mb] + 32 * nb), x, Kind<DT>::value, 16);   // host: out is in the storage type
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s1[r] += x[r]; s2[r] += x[r] * x[r]; }
 #pragma unroll
@@ -1305,7 +1347,7 @@ static hipError_t launch_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
   constexpr TileCfg t = kTiles[TILE];
   constexpr int CPG = conv_cpg(KS);
   constexpr int D = KS == 1 ? 4 : DSX_RING_DEPTH;
-  constexpr int MI = max_it(sizeof(DT) == 2 ? 1 : 0, TILE, KS, S);
+  constexpr int MI = max_it(Kind<DT>::value, TILE, KS, S);
   auto kern = k_conv_mfma<DT, t.MB, t.WM, t.WN, KS, S, CPG, D, MI>;
   if (!ap)
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1335,6 +1377,7 @@ hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& 
   const size_t lds = conv_lds_bytes(dtype, tile, ks, stride, a);
   if (lds == 0 || a.ksplit < 1 || a.n_tiles < 1) return hipErrorInvalidValue;
   return dtype == 1 ? launch_dt<__bf16>(tile, ks, stride, &a, lds, st)
+       : dtype == 2 ? launch_dt<_Float16>(tile, ks, stride, &a, lds, st)
                     : launch_dt<float>(tile, ks, stride, &a, lds, st);
 }
 
@@ -1369,7 +1412,7 @@ static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units pe
 }
 size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   if (!ws_tile_ok(tile) || !(ks == 1 || ks == 3)) return 0;
-  if (ws_tile(tile).NB == 2 && dtype != 1) return 0;
+  if (ws_tile(tile).NB == 2 && dtype == 0) return 0;
   if (conv_lds_bytes(dtype, tile, ks, 1, a) == 0) return 0;
   if (patch_pixels(ks, 1, a) > ws_max_px(tile, ks)) return 0;
   if (a.up && (a.tw_log2 == 0 || a.th_log2 == 0)) return 0;   // the loaders assume an even tile origin when upsampling
@@ -1381,11 +1424,11 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   if (a.tb_log2 != 0 || a.kchunks / conv_cpg(ks) < 2) return 0;   // one image per tile, >= 2 channel groups
   // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
   if ((long long)a.B * a.Ho * a.Wo * std::max(a.out_ld, a.resid_ld) >= (1LL << 31)) return 0;   // 32-bit element offsets
-  const int al = dtype == 1 ? 7 : 3;   // 16-byte rows in elements of the storage type
+  const int al = dtype != 0 ? 7 : 3;   // 16-byte rows in elements of the storage type
   if (a.Cout % (32 * ws_tile(tile).WN * ws_tile(tile).NB) != 0 || (a.out_ld & al) != 0 || (a.resid_ld & al) != 0 ||
       a.C0 + a.C1 > 1024)
     return 0;
-  if (dtype == 1 && !(a.act_bf16 && a.out_bf16)) return 0;   // this kernel reads and writes the storage type only
+  if (dtype != 0 && !(a.act_bf16 && a.out_bf16)) return 0;   // this kernel reads and writes the storage type only
   return total <= 160 * 1024 ? total : 0;
 }
 
@@ -1398,7 +1441,7 @@ static hipError_t launch_ws_one(const ConvArgs* ap, size_t lds, hipStream_t st) 
     constexpr int CPG = conv_cpg(KS);
     // weight ring, in steps: a full group for one N block per wave, half of it (same bytes, same time) for two
     constexpr int D = KS == 1 ? 4 : (t.NB == 2 ? 6 : 18);
-    constexpr int NIT = ws_nit(sizeof(DT) == 2 ? 1 : 0, TILE, KS);
+    constexpr int NIT = ws_nit(Kind<DT>::value, TILE, KS);
     constexpr int P = ws_depth(TILE, KS);
     auto kern = k_conv_ws<DT, t.MB, t.WM, t.WN, t.NB, KS, CPG, D, NIT, P, kWsLoaderWaves>;
     if (!ap)
@@ -1426,22 +1469,25 @@ hipError_t launch_conv_ws(int dtype, int tile, int ks, const ConvArgs& a, hipStr
   const size_t lds = conv_ws_lds_bytes(dtype, tile, ks, a);
   if (lds == 0 || a.ksplit != 1 || a.ws_wg_per_n < 1 || a.stage_mode != 0) return hipErrorInvalidValue;
   if (a.bias && a.film) return hipErrorInvalidValue;   // the planner folds the conv bias into the FiLM bias
-  return dtype == 1 ? launch_ws_dt<__bf16>(tile, ks, &a, lds, st) : launch_ws_dt<float>(tile, ks, &a, lds, st);
+  return dtype == 1 ? launch_ws_dt<__bf16>(tile, ks, &a, lds, st)
+       : dtype == 2 ? launch_ws_dt<_Float16>(tile, ks, &a, lds, st) : launch_ws_dt<float>(tile, ks, &a, lds, st);
 }
 
 hipError_t conv_init() {
   static bool done = false;
   if (done) return hipSuccess;
-  for (int dtype = 0; dtype < 2; ++dtype)
+  for (int dtype = 0; dtype < 3; ++dtype)
     for (int ks = 1; ks <= 3; ks += 2)
       for (int tile = 0; tile < TILE_COUNT; ++tile)
         for (int stride = 1; stride <= 2; ++stride) {
           if (stride == 2 && !(ks == 3 && tile == TILE_64x64)) continue;
           hipError_t e = dtype == 1 ? launch_dt<__bf16>(tile, ks, stride, nullptr, 0, nullptr)
+                       : dtype == 2 ? launch_dt<_Float16>(tile, ks, stride, nullptr, 0, nullptr)
                                     : launch_dt<float>(tile, ks, stride, nullptr, 0, nullptr);
           if (e != hipSuccess) return e;
           if (stride == 1 && ws_tile_ok(tile)) {
             e = dtype == 1 ? launch_ws_dt<__bf16>(tile, ks, nullptr, 0, nullptr)
+              : dtype == 2 ? launch_ws_dt<_Float16>(tile, ks, nullptr, 0, nullptr)
                            : launch_ws_dt<float>(tile, ks, nullptr, 0, nullptr);
             if (e != hipSuccess) return e;
           }
@@ -1475,8 +1521,8 @@ __global__ void k_conv_naive(const NaiveConvArgs na) {
         const size_t so = ((size_t)b * a.Hs + sy) * a.Ws + sx;
         const float* w = na.w + (((size_t)n * na.ks + dy) * na.ks + dx) * C;
         for (int c = 0; c < C; ++c) {
-          float v = c < a.C0 ? (a.act_bf16 ? act_load<__bf16>(a.src0, so * a.C0 + c) : act_load<float>(a.src0, so * a.C0 + c))
-                             : (a.act_bf16 ? act_load<__bf16>(a.src1, so * a.C1 + (c - a.C0)) : act_load<float>(a.src1, so * a.C1 + (c - a.C0)));
+          float v = c < a.C0 ? act_load_kind(a.src0, so * a.C0 + c, a.act_bf16)
+                             : act_load_kind(a.src1, so * a.C1 + (c - a.C0), a.act_bf16);
           if (a.gn_scale) v = v * a.gn_scale[(size_t)b * C + c] + a.gn_shift[(size_t)b * C + c];
           if (a.swish) v = swish_f(v);
           acc = fmaf(v, w[c], acc);
@@ -1486,9 +1532,9 @@ __global__ void k_conv_naive(const NaiveConvArgs na) {
     const size_t opix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
     float v = acc + (a.bias ? a.bias[n] : 0.f);
     if (a.film) v += a.film[(size_t)b * a.film_bs + n];
-    if (a.resid) v += a.act_bf16 ? act_load<__bf16>(a.resid, opix * a.resid_ld + n) : act_load<float>(a.resid, opix * a.resid_ld + n);
+    if (a.resid) v += act_load_kind(a.resid, opix * a.resid_ld + n, a.act_bf16);
     if (na.sigmoid_out) v = 1.0f / (1.0f + __expf(-v));
-    act_store(a.out, opix * a.out_ld + n, v, a.out_bf16 != 0);
+    act_store(a.out, opix * a.out_ld + n, v, a.out_bf16);
   }
 }
 

@@ -16,8 +16,8 @@ namespace dsx {
 struct ConvArgs {
   const void* src0;       // NHWC activations in the storage type: fp32, or bf16 when act_bf16
   const void* src1;
-  int act_bf16;           // src0 / src1 / resid hold bf16 (the bf16-MFMA build stores activations in bf16)
-  int out_bf16;           // out holds bf16 (0 for split-K slabs and the network's final output)
+  int act_bf16;           // storage kind of src0 / src1 / resid: 0 fp32, 1 bf16, 2 fp16 (the MFMA operand type)
+  int out_bf16;           // storage kind of out (0 for split-K slabs and the network's final output)
   int C0, C1;             // channels per source (C1 == 0: single source)
   int B, Hs, Ws;          // source spatial size (before the optional upsample)
   int up;                 // 1: nearest x2 upsample fused into the patch load
@@ -48,7 +48,7 @@ struct ConvArgs {
   float* stat_part;       // fused GroupNorm partials [B][tiles_x*tiles_y*WM][Cout][2] (fp32) or nullptr
   unsigned long long* stamp;  // diagnostic s_memtime stamps of workgroup `stamp_block` (or nullptr)
   int stamp_block;
-  int ablate;             // DSX_ABLATE timing experiments (results are wrong when non-zero)
+  int ablate;             // -DDSX_DIAG builds only: DSX_ABLATE timing experiments (results are wrong when non-zero)
   int ksplit;             // split-K slices (1 = none); slice s writes raw sums to out + s*slab_stride
   int groups_per_split;   // channel groups per slice
   long long slab_stride;  // elements between slabs
@@ -130,16 +130,6 @@ hipError_t launch_temb(const TembArgs& a, hipStream_t st);
 // ---------------------------------------------------------------------------
 // attention (single head, d = C):  S = QK^T/sqrt(C); P = softmax(S); O = PV
 // ---------------------------------------------------------------------------
-struct BgemmArgs {
-  const void* A; int lda; long long sA;    // A[bt][m][k]            (strides in elements)
-  const void* Bm; int ldb; long long sB;   // b_kmajor=0: B[bt][n][k]; 1: B[bt][k][n]
-  int b_kmajor;
-  void* Cm; int ldc; long long sC;
-  int a_bf16, b_bf16, c_bf16;              // element type of each matrix (0: fp32)
-  int M, N, K, batch;
-  float div;                               // C = acc / div
-};
-hipError_t launch_bgemm(const BgemmArgs& a, hipStream_t st);
 // out[m][n] = sum_s slab[s][m][n] + bias[n] + film[b][n] + resid[m][n]   (split-K epilogue)
 struct SplitKReduceArgs {
   const float* slab; int nsplit; long long slab_stride;
@@ -147,11 +137,22 @@ struct SplitKReduceArgs {
   const float* bias; const float* film; int film_bs;
   const void* resid; int resid_ld;
   void* out;
-  int act_bf16;                          // resid and out hold bf16
+  int act_bf16;                          // storage kind of resid and out (0 fp32, 1 bf16, 2 fp16)
   float* stat_part;                      // nullptr, or GroupNorm partials [B][HW/16][N][2] of `out` (N % 64 == 0, HW % 16 == 0)
 };
 hipError_t launch_splitk_reduce(const SplitKReduceArgs& a, hipStream_t st);
-hipError_t launch_softmax_rows(float* S, long long rows, int L, hipStream_t st);
+
+// fused single-head attention (dsx_attn.hip): out[b][i][:] = softmax_j(q_i . k_j / div) . v_j ; no L x L tensor in HBM.
+// q / k / v: token-major rows of `ld` elements (the three thirds of the qkv conv's output), out: rows of `ldo`.
+struct AttnArgs {
+  const void* q; const void* k; const void* v; int ld;
+  void* out; int ldo;
+  int storage;            // element type of q, k, v and out: 0 fp32, 1 bf16, 2 fp16
+  int B, L, C;            // images, tokens per image, head dimension (= channels)
+  float div, inv_div;     // sqrt(C) and its reciprocal
+};
+bool attn_supported(int C, int L);
+hipError_t launch_attn(const AttnArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // layout, sampler update, RNG, tiling
@@ -163,11 +164,15 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H
 
 struct UpdateArgs {
   float* x;               // state, NHWC [B][H][W][C], always fp32
-  void* x_act;            // the first conv's copy of the state in the activation storage type (bf16 build),
+  void* x_act;            // the first conv's copy of the state in the activation storage type (16-bit builds),
                           // or nullptr when the conv reads `x` itself
+  int x_act_kind;         // its storage kind (1 bf16, 2 fp16)
   const float* net;       // UNet output, NHWC
-  const float* noise;     // nullptr -> Philox; else [steps][B][C][H][W] (NCHW, reference draw order)
-  unsigned long long seed;
+  int use_noise;          // 0 -> Philox normals keyed by (seed, step); 1 -> injected draws
+  // per-call values live in device memory so that one captured graph serves every call:
+  // loop_params[0] = Philox seed, loop_params[1] = address of the injected noise [steps][B][C][H][W] (NCHW,
+  // reference draw order)
+  const unsigned long long* loop_params;
   const float* tab;       // device table [6][n_steps]: tcond,a,b,c1,c2,sigma
   int n_steps;            // column stride of `tab` (its capacity)
   const int* step_ctr;

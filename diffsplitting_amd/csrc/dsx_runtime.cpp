@@ -315,13 +315,27 @@ static inline uint16_t f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
-// OIHW fp32 -> [nblk][kchunk][tap][half][lane][16 B] (see dsx_conv.hip header)
-static void pack_conv(const float* w, int cout, int cin, int ks, int dtype, std::vector<char>& dst,
-                      int& kchunks, int& nblocks) {
-  const int KC = dtype == 1 ? 32 : 16, EPL = dtype == 1 ? 8 : 4, taps = ks * ks;
+// packed geometry of one conv: 64-byte input-channel chunks (padded to the staging group) and 32-channel N blocks
+static void conv_geometry(int cout, int cin, int ks, int dtype, int& kchunks, int& nblocks) {
+  const int KC = dtype != DSX_DTYPE_F32 ? 32 : 16;
   const int mult = conv_chunk_multiple(ks);
   kchunks = ((cin + KC - 1) / KC + mult - 1) / mult * mult;
   nblocks = (cout + 31) / 32;
+}
+
+// fp32 -> fp16 round-to-nearest-even
+static inline uint16_t f2h(float f) {
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+
+// OIHW fp32 -> [nblk][kchunk][tap][half][lane][16 B] (see dsx_conv.hip header)
+static void pack_conv(const float* w, int cout, int cin, int ks, int dtype, std::vector<char>& dst,
+                      int& kchunks, int& nblocks) {
+  const int KC = dtype != DSX_DTYPE_F32 ? 32 : 16, EPL = dtype != DSX_DTYPE_F32 ? 8 : 4, taps = ks * ks;
+  conv_geometry(cout, cin, ks, dtype, kchunks, nblocks);
   dst.assign((size_t)nblocks * kchunks * taps * 2 * 64 * 16, 0);
   for (int nb = 0; nb < nblocks; ++nb)
     for (int kc = 0; kc < kchunks; ++kc)
@@ -337,7 +351,8 @@ static void pack_conv(const float* w, int cout, int cin, int ks, int dtype, std:
               const int c = kc * KC + (KC / 2) * fs + EPL * h + j;
               float v = 0.f;
               if (n < cout && c < cin) v = w[((size_t)n * cin + c) * taps + tap];
-              if (dtype == 1) { uint16_t b = f2bf(v); memcpy(p + 2 * j, &b, 2); }
+              if (dtype == DSX_DTYPE_BF16) { uint16_t b = f2bf(v); memcpy(p + 2 * j, &b, 2); }
+              else if (dtype == DSX_DTYPE_F16) { uint16_t b = f2h(v); memcpy(p + 2 * j, &b, 2); }
               else memcpy(p + 4 * j, &v, 4);
             }
           }
@@ -345,7 +360,7 @@ static void pack_conv(const float* w, int cout, int cin, int ks, int dtype, std:
 
 extern "C" int dsx_model_finalize(dsx_model* m, int dtype) {
   if (!m) return fail(DSX_ERR_INVALID, "null model");
-  if (dtype != DSX_DTYPE_F32 && dtype != DSX_DTYPE_BF16) return fail(DSX_ERR_INVALID, "bad dtype");
+  if (dtype != DSX_DTYPE_F32 && dtype != DSX_DTYPE_BF16 && dtype != DSX_DTYPE_F16) return fail(DSX_ERR_INVALID, "bad dtype");
   for (int i = 0; i < (int)m->params.size(); ++i) {
     if (m->params[i].set || i == m->p_invfreq) continue;  // inv_freq is derived below if absent
     return fail(DSX_ERR_MISSING, "parameter %s was never set", m->params[i].name.c_str());
@@ -470,11 +485,12 @@ extern "C" double dsx_model_flops(const dsx_model* m, int H, int W) {
 namespace {
 
 struct Tensor {
-  void* p = nullptr;       // NHWC, fp32 or (bf16 build) bf16
+  void* p = nullptr;       // NHWC in the storage type `st`
   int C = 0, H = 0, W = 0;
   int id = -1;             // index into dsx_exec::stats (copies of a Tensor share it)
-  bool bf16 = false;
-  char* at(size_t elem) const { return (char*)p + elem * (bf16 ? 2 : 4); }
+  int st = 0;              // storage kind: 0 fp32, 1 bf16, 2 fp16 (DSX_DTYPE_*)
+  int esz() const { return st ? 2 : 4; }
+  char* at(size_t elem) const { return (char*)p + elem * esz(); }
 };
 struct StatInfo {          // GroupNorm partial sums of one tensor, produced at most once
   void* part = nullptr;    // double [B][nchunk][C][2] (k_chan_stats) or float (fused into the conv epilogue)
@@ -514,8 +530,9 @@ struct dsx_exec {
   int table_cap = 0;
   std::vector<float> table_host;
   bool temb_from_table = false;
-  const float* upd_noise = nullptr;
-  unsigned long long upd_seed = 0;
+  unsigned long long* loop_params = nullptr;   // device {seed, noise address}: per-call values the captured step reads
+  unsigned long long loop_params_host[2] = {0, 0};
+  hipStream_t last_stream = nullptr;           // stream of the most recent graph launches
   dsx_step_table cur_tab{};
   // graph
   hipGraphExec_t graph_exec = nullptr;
@@ -551,8 +568,8 @@ static char* ws_alloc(dsx_exec* ex, size_t bytes) {
 static Tensor new_tensor(dsx_exec* ex, int C, int H, int W, bool f32 = false) {
   Tensor t;
   t.C = C; t.H = H; t.W = W;
-  t.bf16 = ex->m->dtype == 1 && !f32;
-  t.p = ws_alloc(ex, (size_t)ex->B * H * W * C * (t.bf16 ? 2 : 4));
+  t.st = f32 ? 0 : ex->m->dtype;
+  t.p = ws_alloc(ex, (size_t)ex->B * H * W * C * t.esz());
   t.id = (int)ex->stats.size();
   ex->stats.push_back(StatInfo());
   return t;
@@ -596,7 +613,11 @@ static bool tile_geometry(int dtype, int tile, int ks, int stride, const ConvArg
   c.n_tiles = (c.nblocks * 32 + ti.BN - 1) / ti.BN;
   c.ksplit = 1; c.groups_per_split = a.kchunks / conv_chunk_multiple(ks); c.slab_stride = 0;
   c.lds_row = conv_lds_row(ks, stride, c.tw_log2);
-  c.ablate = getenv("DSX_ABLATE") ? atoi(getenv("DSX_ABLATE")) : 0;
+#ifdef DSX_DIAG
+  c.ablate = getenv("DSX_ABLATE") ? atoi(getenv("DSX_ABLATE")) : 0;   // diagnostic build only
+#else
+  c.ablate = 0;
+#endif
   return conv_lds_bytes(dtype, tile, ks, stride, c) != 0;
 }
 
@@ -687,11 +708,11 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   a.Ho = s.out.H; a.Wo = s.out.W;
   a.gn_scale = s.gn_scale; a.gn_shift = s.gn_shift; a.swish = s.swish ? 1 : 0;
   a.has_gn = s.has_gn ? 1 : 0;
-  a.act_bf16 = ex->m->dtype == 1 ? 1 : 0;
-  a.out_bf16 = s.out.bf16 ? 1 : 0;
+  a.act_bf16 = ex->m->dtype;   // storage kind of the sources / residual
+  a.out_bf16 = s.out.st;
   {
-    const int gw = conv_chunk_multiple(s.w->ks) * (ex->m->dtype == 1 ? 32 : 16);  // channels per staged group
-    const int um = ex->m->dtype == 1 ? 7 : 3;                                       // channels per 16-byte unit - 1
+    const int gw = conv_chunk_multiple(s.w->ks) * (ex->m->dtype != 0 ? 32 : 16);  // channels per staged group
+    const int um = ex->m->dtype != 0 ? 7 : 3;                                       // channels per 16-byte unit - 1
     a.stage_mode = ((a.C0 & um) || (a.C1 & um)) ? 2 : ((a.C1 == 0 || a.C0 % gw == 0) ? 0 : 1);
   }
   a.wpack = s.w->pack; a.bias = s.bias_in_film ? nullptr : s.w->bias;
@@ -700,6 +721,16 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   a.out = s.out.p; a.out_ld = s.out.C; a.Cout = s.w->cout;
   a.nblocks = s.w->nblocks; a.kchunks = s.w->kchunks;
   if (a.C0 + a.C1 != s.w->cin) return fail(DSX_ERR_INVALID, "conv channel mismatch");
+  {
+    // the conv kernels address their sources with 32-bit byte offsets (0x80000000 = forced out of bounds, the
+    // zero padding): a source tensor of 2 GiB or more would silently read as zeros
+    const long long esz_src = ex->m->dtype != DSX_DTYPE_F32 ? 2 : 4;
+    const long long src_bytes = (long long)a.B * a.Hs * a.Ws * std::max(a.C0, a.C1) * esz_src;
+    if (src_bytes >= (1LL << 31))
+      return fail(DSX_ERR_INVALID,
+                  "conv source of %lld bytes (B=%d, %dx%d, %d channels) exceeds the 2 GiB the kernels address; "
+                  "use a smaller batch per executor", src_bytes, a.B, a.Hs, a.Ws, std::max(a.C0, a.C1));
+  }
   const int dtype = ex->m->dtype, ks = s.w->ks, stride = s.stride;
   int tile = -1;
   const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
@@ -750,8 +781,8 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   const double npix = (double)a.B * a.Ho * a.Wo;
   const double cin = a.C0 + a.C1;
   const double flops = 2.0 * npix * a.Cout * cin * ks * ks;
-  const double wbytes = (double)a.Cout * cin * ks * ks * (dtype == 1 ? 2 : 4);
-  const double esz = dtype == 1 ? 2.0 : 4.0;   // activation element size in HBM
+  const double wbytes = (double)a.Cout * cin * ks * ks * (dtype != 0 ? 2 : 4);
+  const double esz = dtype != 0 ? 2.0 : 4.0;   // activation element size in HBM
   const double bytes = esz * ((double)a.B * a.Hs * a.Ws * cin + npix * a.Cout * (a.resid ? 1 : 0)) +
                        (a.out_bf16 ? 2.0 : 4.0) * npix * a.Cout + wbytes;
   if (mfma_ok) {
@@ -816,7 +847,7 @@ static void plan_stats(dsx_exec* ex, const Tensor& t) {
   ex->launches++;
   if (ex->sizing) return;
   const void* x = t.p; double* part = (double*)si.part;
-  const int B = ex->B, C = t.C, xbf = t.bf16 ? 1 : 0;
+  const int B = ex->B, C = t.C, xbf = t.st;
   add_op(ex, DSX_OP_GN_STATS, fmt("gn_stats C=%d @%dx%d", C, t.H, t.W), 0.0, (xbf ? 2.0 : 4.0) * B * HW * C,
          [=](hipStream_t st) { return launch_chan_stats(x, xbf, B, HW, C, nchunk, part, st); });
 }
@@ -880,28 +911,17 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   ConvSpec cq{};
   cq.w = &md.qkv; cq.x0 = o; cq.gn_scale = sa; cq.gn_shift = ha; cq.has_gn = true; cq.out = qkv;
   if ((rc = plan_conv(ex, cq))) return rc;
-  float* S = (float*)ws_alloc(ex, (size_t)B * L * L * sizeof(float));
   Tensor av = new_tensor(ex, C, H, W);
-  ex->launches += 3;
+  ex->launches += 1;
+  if (!attn_supported(C, L)) return fail(DSX_ERR_INVALID, "attention with head dimension %d is not supported (4..1024, multiple of 4)", C);
   if (!ex->sizing) {
-    BgemmArgs g1{};
-    const int abf = qkv.bf16 ? 1 : 0;
-    const double esz = abf ? 2.0 : 4.0;
-    g1.A = qkv.p; g1.lda = 3 * C; g1.sA = (long long)L * 3 * C; g1.a_bf16 = abf;
-    g1.Bm = qkv.at(C); g1.ldb = 3 * C; g1.sB = g1.sA; g1.b_kmajor = 0; g1.b_bf16 = abf;
-    g1.Cm = S; g1.ldc = L; g1.sC = (long long)L * L; g1.c_bf16 = 0;
-    g1.M = L; g1.N = L; g1.K = C; g1.batch = B; g1.div = sqrtf((float)C);
-    add_op(ex, DSX_OP_ATTN_GEMM, fmt("attn QK^T L=%d d=%d", L, C), 2.0 * B * L * (double)L * C,
-           B * (esz * 2.0 * L * C + 4.0 * (double)L * L), [=](hipStream_t st) { return launch_bgemm(g1, st); });
-    add_op(ex, DSX_OP_SOFTMAX, fmt("softmax L=%d", L), 0.0, 8.0 * B * (double)L * L,
-           [=](hipStream_t st) { return launch_softmax_rows(S, (long long)B * L, L, st); });
-    BgemmArgs g2{};
-    g2.A = S; g2.lda = L; g2.sA = (long long)L * L; g2.a_bf16 = 0;
-    g2.Bm = qkv.at(2 * (size_t)C); g2.ldb = 3 * C; g2.sB = (long long)L * 3 * C; g2.b_kmajor = 1; g2.b_bf16 = abf;
-    g2.Cm = av.p; g2.ldc = C; g2.sC = (long long)L * C; g2.c_bf16 = av.bf16 ? 1 : 0;
-    g2.M = L; g2.N = C; g2.K = L; g2.batch = B; g2.div = 1.0f;
-    add_op(ex, DSX_OP_ATTN_GEMM, fmt("attn PV L=%d d=%d", L, C), 2.0 * B * L * (double)L * C,
-           B * (esz * 2.0 * L * C + 4.0 * (double)L * L), [=](hipStream_t st) { return launch_bgemm(g2, st); });
+    AttnArgs g{};
+    g.q = qkv.p; g.k = qkv.at(C); g.v = qkv.at(2 * (size_t)C); g.ld = 3 * C;
+    g.out = av.p; g.ldo = C; g.storage = qkv.st;
+    g.B = B; g.L = L; g.C = C; g.div = sqrtf((float)C); g.inv_div = 1.0f / g.div;
+    const double esz = qkv.st ? 2.0 : 4.0;
+    add_op(ex, DSX_OP_ATTN_GEMM, fmt("attn fused L=%d d=%d", L, C), 4.0 * B * L * (double)L * C,
+           B * esz * 4.0 * L * C, [=](hipStream_t st) { return launch_attn(g, st); });
   }
   Tensor o2 = new_tensor(ex, C, H, W);
   ConvSpec co{};
@@ -921,12 +941,13 @@ static int build_plan(dsx_exec* ex) {
   ex->launches = 0;
   const int B = ex->B;
   ex->step_ctr = (int*)ws_alloc(ex, 256);
+  ex->loop_params = (unsigned long long*)(ex->sizing ? nullptr : (char*)ex->step_ctr + 64);
   ex->time_buf = (float*)ws_alloc(ex, (size_t)B * sizeof(float));
   ex->film = m->F ? (float*)ws_alloc(ex, (size_t)B * m->F * sizeof(float)) : nullptr;
   ex->in_cond = Tensor();
   if (ex->cond_c) ex->in_cond = new_tensor(ex, ex->cond_c, ex->H, ex->W);
   ex->in_x = new_tensor(ex, ex->x_c, ex->H, ex->W);
-  ex->x_state = ex->in_x.bf16 ? (float*)ws_alloc(ex, (size_t)B * ex->H * ex->W * ex->x_c * sizeof(float))
+  ex->x_state = ex->in_x.st ? (float*)ws_alloc(ex, (size_t)B * ex->H * ex->W * ex->x_c * sizeof(float))
                               : (float*)ex->in_x.p;
   std::vector<Tensor> feats;
   Tensor x;
@@ -976,7 +997,7 @@ static int build_plan(dsx_exec* ex) {
     }
   }
   ex->out = x;
-  if (ex->out.bf16) return fail(DSX_ERR_STATE, "internal error: the network output must be an fp32 tensor");
+  if (ex->out.st) return fail(DSX_ERR_STATE, "internal error: the network output must be an fp32 tensor");
   if (ex->overflow)
     return fail(DSX_ERR_STATE, "internal error: the planning pass needs more workspace than the sizing pass reserved");
   return DSX_OK;
@@ -1002,12 +1023,53 @@ extern "C" int dsx_exec_create(dsx_model* m, int B, int H, int W, int cond_chann
                 hipGetErrorString(e));
   }
   ex->sizing = false;
+  const size_t sized = ex->ws_used;
   rc = build_plan(ex);
+  if (rc == DSX_OK && ex->ws_used != sized)
+    rc = fail(DSX_ERR_STATE, "internal error: sizing pass reserved %zu bytes, planning pass used %zu", sized, ex->ws_used);
   if (rc) { (void)hipFree(ex->ws); delete ex; return rc; }
   e = hipMemset(ex->step_ctr, 0, 256);
   if (e != hipSuccess) { (void)hipFree(ex->ws); delete ex; return fail(DSX_ERR_HIP, "hipMemset failed"); }
   *out = ex;
   return DSX_OK;
+}
+
+// Host-only: both planner passes for (cfg, dtype, B, H, W) without a device (the workspace base is a fake
+// address that is never dereferenced).  Tests use it to pin that sizing and planning agree under every tile
+// preference setting.
+extern "C" int dsx_plan_dry_run(const dsx_unet_cfg* cfg, int dtype, int B, int H, int W, int cond_channels,
+                                size_t* sizing_bytes, size_t* planning_bytes, int* launches) {
+  if (!cfg || B < 1 || H < 1 || W < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  if (dtype != DSX_DTYPE_F32 && dtype != DSX_DTYPE_BF16 && dtype != DSX_DTYPE_F16) return fail(DSX_ERR_INVALID, "bad dtype");
+  dsx_model* m = nullptr;
+  int rc = dsx_model_create(cfg, &m);
+  if (rc) return rc;
+  if (cond_channels < 0 || cond_channels >= m->cfg.in_channel) { dsx_model_destroy(m); return fail(DSX_ERR_INVALID, "bad cond_channels"); }
+  m->dtype = dtype;
+  for (auto& md : m->mods)
+    for (ConvW* c : {&md.conv, &md.conv1, &md.conv2, &md.res, &md.qkv, &md.out})
+      if (c->pw >= 0) conv_geometry(c->cout, c->cin, c->ks, dtype, c->kchunks, c->nblocks);
+  dsx_exec* ex = new dsx_exec();
+  ex->m = m; ex->B = B; ex->H = H; ex->W = W;
+  ex->cond_c = cond_channels; ex->x_c = m->cfg.in_channel - cond_channels;
+  ex->sizing = true;
+  rc = build_plan(ex);
+  const size_t sized = ex->ws_used;
+  size_t planned = 0;
+  if (rc == DSX_OK) {
+    ex->sizing = false;
+    ex->ws = (char*)(uintptr_t)0x100000000ull;   // never dereferenced: no launch happens
+    ex->ws_bytes = ~(size_t)0 >> 1;
+    rc = build_plan(ex);
+    planned = ex->ws_used;
+  }
+  if (sizing_bytes) *sizing_bytes = sized;
+  if (planning_bytes) *planning_bytes = planned;
+  if (launches) *launches = ex->launches;
+  ex->ws = nullptr;
+  delete ex;
+  dsx_model_destroy(m);
+  return rc;
 }
 
 extern "C" void dsx_exec_destroy(dsx_exec* ex) {
@@ -1154,12 +1216,12 @@ static int load_inputs(dsx_exec* ex, const float* cond_nchw, const float* x_nchw
   if (ex->cond_c) {
     if (!cond_nchw) return fail(DSX_ERR_INVALID, "this executor was created with cond_channels > 0");
     const int ctot = (cond_nchw == x_nchw) ? x_total_c : ex->cond_c;
-    HIP_TRY(dsx::launch_nchw_slice_to_nhwc(cond_nchw, ex->in_cond.p, ex->in_cond.bf16 ? 1 : 0, ex->B, ex->cond_c, ctot,
+    HIP_TRY(dsx::launch_nchw_slice_to_nhwc(cond_nchw, ex->in_cond.p, ex->in_cond.st, ex->B, ex->cond_c, ctot,
                                            0, HW, st));
   }
-  HIP_TRY(dsx::launch_nchw_slice_to_nhwc(x_nchw, ex->in_x.p, ex->in_x.bf16 ? 1 : 0, ex->B, ex->x_c, x_total_c, x_c_off,
+  HIP_TRY(dsx::launch_nchw_slice_to_nhwc(x_nchw, ex->in_x.p, ex->in_x.st, ex->B, ex->x_c, x_total_c, x_c_off,
                                          HW, st));
-  if (ex->in_x.bf16)   // the sampler state itself stays fp32
+  if (ex->in_x.st)   // the sampler state itself stays fp32
     HIP_TRY(dsx::launch_nchw_slice_to_nhwc(x_nchw, ex->x_state, 0, ex->B, ex->x_c, x_total_c, x_c_off, HW, st));
   return DSX_OK;
 }
@@ -1169,7 +1231,10 @@ static int ensure_table(dsx_exec* ex, const dsx_step_table* tab) {
   const int T = tab->n_steps;
   if (T > ex->table_cap) {
     // the table's column stride (= capacity) is baked into captured graphs: drop them
-    if (ex->graph_exec) { (void)hipGraphExecDestroy(ex->graph_exec); ex->graph_exec = nullptr; }
+    if (ex->graph_exec) {
+      if (ex->last_stream) HIP_TRY(hipStreamSynchronize(ex->last_stream));
+      (void)hipGraphExecDestroy(ex->graph_exec); ex->graph_exec = nullptr;
+    }
     if (ex->graph) { (void)hipGraphDestroy(ex->graph); ex->graph = nullptr; }
     if (ex->table) (void)hipFree(ex->table);
     ex->table = nullptr;
@@ -1185,13 +1250,12 @@ static int ensure_table(dsx_exec* ex, const dsx_step_table* tab) {
   return DSX_OK;
 }
 
-static int enqueue_step(dsx_exec* ex, const dsx_step_table* tab, const float* noise, uint64_t seed,
-                        hipStream_t st) {
+static int enqueue_step(dsx_exec* ex, const dsx_step_table* tab, bool use_noise, hipStream_t st) {
   int rc = run_unet(ex, true, 1, st);
   if (rc) return rc;
   UpdateArgs u{};
-  u.x = ex->x_state; u.x_act = ex->in_x.bf16 ? ex->in_x.p : nullptr;
-  u.net = (const float*)ex->out.p; u.noise = noise; u.seed = seed;
+  u.x = ex->x_state; u.x_act = ex->in_x.st ? ex->in_x.p : nullptr; u.x_act_kind = ex->in_x.st;
+  u.net = (const float*)ex->out.p; u.use_noise = use_noise ? 1 : 0; u.loop_params = ex->loop_params;
   u.tab = ex->table; u.n_steps = ex->table_cap; u.step_ctr = ex->step_ctr;
   u.predict_eps = tab->predict_eps; u.clip = tab->clip;
   u.B = ex->B; u.C = ex->x_c; u.H = ex->H; u.W = ex->W;
@@ -1218,24 +1282,28 @@ extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const fl
   HIP_TRY(hipMemsetAsync(ex->step_ctr, 0, 4, st));
   if ((rc = load_inputs(ex, cond, x, ex->x_c, 0, st))) return rc;
 
+  // per-call values (seed, noise address) go to device memory: the captured step does not bake them in
+  ex->loop_params_host[0] = seed;
+  ex->loop_params_host[1] = (unsigned long long)(uintptr_t)noise;
+  HIP_TRY(hipMemcpyAsync(ex->loop_params, ex->loop_params_host, 16, hipMemcpyHostToDevice, st));
+
   const size_t snap_elems = (size_t)ex->B * ex->x_c * ex->H * ex->W;
   bool graph_ok = false;
   if (use_graph) {
-    // the captured step bakes in: mode flags, noise pointer, seed (not the step count)
-    std::vector<float> sig = {(float)tab->predict_eps, (float)tab->clip};
-    uint64_t np = (uint64_t)(uintptr_t)noise;
-    float f[4];
-    memcpy(f, &np, 8); memcpy(f + 2, &seed, 8);
-    sig.insert(sig.end(), f, f + 4);
-    if (!ex->graph_exec || sig.size() != ex->graph_sig.size() ||
-        memcmp(sig.data(), ex->graph_sig.data(), sig.size() * 4)) {
-      if (ex->graph_exec) { (void)hipGraphExecDestroy(ex->graph_exec); ex->graph_exec = nullptr; }
+    // the captured step bakes in the mode flags only (not the step count, the seed or the noise address)
+    std::vector<float> sig = {(float)tab->predict_eps, (float)tab->clip, noise ? 1.f : 0.f};
+    if (!ex->graph_exec || sig != ex->graph_sig) {
+      if (ex->graph_exec) {
+        // a replaced executable graph may still have launches queued: wait for them before destroying it
+        if (ex->last_stream) HIP_TRY(hipStreamSynchronize(ex->last_stream));
+        (void)hipGraphExecDestroy(ex->graph_exec); ex->graph_exec = nullptr;
+      }
       if (ex->graph) { (void)hipGraphDestroy(ex->graph); ex->graph = nullptr; }
       hipStream_t cs;
       HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
-        rc = enqueue_step(ex, tab, noise, seed, cs);
+        rc = enqueue_step(ex, tab, noise != nullptr, cs);
         hipError_t e2 = hipStreamEndCapture(cs, &ex->graph);
         if (rc == DSX_OK && e2 == hipSuccess) e2 = hipGraphInstantiate(&ex->graph_exec, ex->graph, nullptr, nullptr, 0);
         if (rc != DSX_OK || e2 != hipSuccess) {
@@ -1252,11 +1320,12 @@ extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const fl
     }
     graph_ok = ex->graph_exec != nullptr;
     if (!graph_ok) return fail(DSX_ERR_HIP, "hipGraph capture of the sampling step failed");
+    ex->last_stream = st;
   }
   int snap_i = 0;
   for (int s = 0; s < T; ++s) {
     if (graph_ok) HIP_TRY(hipGraphLaunch(ex->graph_exec, st));
-    else if ((rc = enqueue_step(ex, tab, noise, seed, st))) return rc;
+    else if ((rc = enqueue_step(ex, tab, noise != nullptr, st))) return rc;
     while (snap_i < n_snap && snap_steps[snap_i] == s) {
       HIP_TRY(launch_nhwc_to_nchw(ex->x_state, snaps + (size_t)snap_i * snap_elems, ex->B, ex->x_c, ex->H,
                                   ex->W, st));
@@ -1300,7 +1369,7 @@ extern "C" int dsx_time_predictor_forward(dsx_exec* ex, const float* x, float* t
   if ((rc = run_unet(ex, false, 1, st))) return rc;
   NaiveConvArgs na{};
   na.c.src0 = ex->in_x.p; na.c.C0 = ex->x_c; na.c.C1 = 0;
-  na.c.act_bf16 = ex->in_x.bf16 ? 1 : 0; na.c.out_bf16 = 0;
+  na.c.act_bf16 = ex->in_x.st; na.c.out_bf16 = 0;
   na.c.B = ex->B; na.c.Hs = ex->H; na.c.Ws = ex->W; na.c.Ho = ex->H; na.c.Wo = ex->W;
   na.c.bias = ex->tp_b; na.c.out = ex->tp_mask; na.c.out_ld = 1; na.c.Cout = 1;
   na.w = ex->tp_w; na.ks = 7; na.stride = 1; na.sigmoid_out = 1;

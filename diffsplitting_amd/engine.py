@@ -48,6 +48,25 @@ def make_cfg(flavour, in_channel, out_channel, inner_channel, norm_groups, chann
     return cfg
 
 
+def dtype_code(dtype):
+    """'f32' | 'bf16' | 'f16' (or the torch dtypes) -> DSX_DTYPE_*: the MFMA operand / activation storage type."""
+    if dtype in ("bf16", torch.bfloat16):
+        return _lib.DTYPE_BF16
+    if dtype in ("f16", "fp16", torch.float16):
+        return _lib.DTYPE_F16
+    if dtype in ("f32", "fp32", torch.float32, None):
+        return _lib.DTYPE_F32
+    raise DsxError(f"unknown compute dtype {dtype!r} (f32, bf16, f16)")
+
+
+def plan_dry_run(cfg, dtype, B, H, W, cond_channels=0):
+    """Host-only planner check (no GPU): (sizing_bytes, planning_bytes, launches) of dsx_plan_dry_run."""
+    a, b, n = C.c_size_t(), C.c_size_t(), C.c_int()
+    check(lib.dsx_plan_dry_run(C.byref(cfg), dtype_code(dtype), int(B), int(H), int(W), int(cond_channels),
+                               C.byref(a), C.byref(b), C.byref(n)))
+    return int(a.value), int(b.value), int(n.value)
+
+
 def _dptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -116,7 +135,7 @@ class UNetEngine:
 
     def finalize(self, dtype="f32"):
         _lib.require_gpu()
-        code = _lib.DTYPE_BF16 if dtype in ("bf16", torch.bfloat16) else _lib.DTYPE_F32
+        code = dtype_code(dtype)
         if self._finalized_dtype != code:
             self._drop_execs()
             check(lib.dsx_model_finalize(self._h, code))

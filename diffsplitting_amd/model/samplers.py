@@ -88,7 +88,8 @@ class GaussianSampler(_SamplerBase):
             cond = x_in.to(dev).float()
             shape = (cond.shape[0], self.channels) + tuple(cond.shape[2:])
         img = self._draw(shape, dev)
-        first = img if cond is None else cond.repeat((1, self.channels // cond.shape[1], 1, 1))
+        # the loop updates `img` in place: keep a copy of the initial noise for ret_img[0] (sr3 diffusion.py:183-185)
+        first = (img.clone() if continous else None) if cond is None else cond.repeat((1, self.channels // cond.shape[1], 1, 1))
         noise = None
         if self.noise_source is not None:  # reference draw order: one per step, none at t == 0 (sr3)
             n_draw = T - 1 if self.kind == "sr3" else T

@@ -37,7 +37,7 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=str, default="2,512,512", help="N,H,W of synthetic frames")
     ap.add_argument("--steps", type=int, default=None, help="override beta_schedule.val.n_timestep")
     ap.add_argument("--batch-tiles", type=int, default=8)
-    ap.add_argument("--dtype", type=str, default=None, choices=["f32", "bf16"])
+    ap.add_argument("--dtype", type=str, default=None, choices=["f32", "bf16", "f16"])
     args = ap.parse_args(argv)
     if args.phase == "train":
         raise SystemExit("training is out of scope of the MI355X sampling engine; use -p val")
@@ -48,7 +48,12 @@ def main(argv=None):
     opt = Logger.parse(args)
     if args.dtype:
         opt["model"]["compute_dtype"] = args.dtype
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    # -gpu selects the device(s): rank r of a torchrun launch drives gpu_ids[r] (the reference exports
+    # CUDA_VISIBLE_DEVICES=gpu_ids instead, core/logger.py:59-65; mapping the index keeps one process per GPU
+    # working without touching the environment after HIP may have been initialised)
+    ids = list(opt["gpu_ids"] or [0])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(ids[local % len(ids)])
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.backends.cudnn.benchmark = True
 

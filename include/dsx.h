@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSX_ABI_VERSION 1
+#define DSX_ABI_VERSION 2
 
 typedef enum dsx_status {
   DSX_OK = 0,
@@ -44,7 +44,9 @@ int dsx_device_count(void);
 /* ------------------------------------------------------------------ UNet */
 
 enum { DSX_FLAVOUR_SR3 = 0, DSX_FLAVOUR_DDPM = 1 };
-enum { DSX_DTYPE_F32 = 0, DSX_DTYPE_BF16 = 1 };   /* MFMA operand type; accumulation is always f32 */
+/* MFMA operand type = activation storage type in HBM; accumulation, GroupNorm statistics and the sampler state are
+ * always f32.  F16 is what config/splitting_hagen_indi_joint.json is quoted on (BASELINE "fp16"). */
+enum { DSX_DTYPE_F32 = 0, DSX_DTYPE_BF16 = 1, DSX_DTYPE_F16 = 2 };
 
 /* Mirrors the keyword arguments of UNet.__init__
  * (model/sr3_modules/unet.py:161-174, model/ddpm_modules/unet.py:150-162). */
@@ -100,12 +102,18 @@ typedef struct dsx_exec dsx_exec;
 int dsx_exec_create(dsx_model* m, int B, int H, int W, int cond_channels, dsx_exec** out);
 void dsx_exec_destroy(dsx_exec* ex);
 size_t dsx_exec_workspace_bytes(const dsx_exec* ex);
+/* Host-only (no device needed): runs the planner's sizing pass and its planning pass for this geometry and
+ * reports the workspace bytes each of them walked and the launch count.  The two must agree; dsx_exec_create
+ * fails if they do not.  Lets CPU tests pin the planner under every tile-preference environment setting. */
+int dsx_plan_dry_run(const dsx_unet_cfg* cfg, int compute_dtype, int B, int H, int W, int cond_channels,
+                     size_t* sizing_bytes, size_t* planning_bytes, int* launches);
 int dsx_exec_num_launches(const dsx_exec* ex);
 
 /* Launch-level introspection for measurement (bench.py roofline): the plan's
  * launches in order, what each computes, and an eager hipEvent-timed replay. */
 enum { DSX_OP_CONV_MFMA = 0, DSX_OP_CONV_NAIVE = 1, DSX_OP_GN_STATS = 2, DSX_OP_GN_FINALIZE = 3,
-       DSX_OP_ATTN_GEMM = 4, DSX_OP_SOFTMAX = 5, DSX_OP_SPLITK_REDUCE = 6 };
+       DSX_OP_ATTN_GEMM = 4 /* the fused attention kernel */, DSX_OP_SOFTMAX = 5 /* unused since ABI 2 */,
+       DSX_OP_SPLITK_REDUCE = 6, DSX_OP_STREAM_CONV = 7 /* few-channel first / last conv */ };
 int dsx_exec_num_ops(const dsx_exec* ex);
 int dsx_exec_op_info(const dsx_exec* ex, int index, char* desc_buf, int desc_cap, int* kind,
                      double* flops, double* bytes);

@@ -28,6 +28,41 @@ UNET_CASES = {
                               channel_mults=(1, 2, 4, 8), attn_res=(), res_blocks=1, image_size=32)),
 }
 
+# Full-size cases at the shapes BASELINE.json names (C3 / C4 / C5): fixtures hold digests of the reference's
+# outputs (crops, strided grids, per-channel sums), the GPU tests compare whole tensors with the oracle.
+_HAGEN = dict(inner_channel=16, norm_groups=16, channel_mults=(1, 2, 4, 8), attn_res=(), res_blocks=1, image_size=32)
+FULLSIZE_CASES = {
+    # config/sr_sr3_64_512.json: mults [1,2,4,8,16], 2048->1024 convs, bottleneck attention L=1024 d=1024, GN16, rb=1
+    "c4_sr3_512": dict(flavour="sr3", B=1, H=512, W=512,
+                       cfg=dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=16,
+                                channel_mults=(1, 2, 4, 8, 16), attn_res=(), res_blocks=1, image_size=512)),
+    # config/splitting_hagen_indi.json on one 512^2 tile: bottleneck attention L=4096 d=128
+    "c3_hagen_512": dict(flavour="ddpm", B=1, H=512, W=512, cfg=dict(in_channel=2, out_channel=2, **_HAGEN)),
+    # config/splitting_hagen_indi_joint.json: two 1->1 UNets; config/splitting_hagen_time_predictor.json: the TimePredictor
+    "c5_joint_512": dict(flavour="ddpm", B=1, H=512, W=512, cfg=dict(in_channel=1, out_channel=1, **_HAGEN)),
+}
+
+
+def digest(y):
+    """Size-bounded digest of an (N, C, H, W) array: centre crop, strided grid over the whole image (borders
+    included), a corner, and float64 per-(n, c) sums / sums of squares."""
+    import numpy as np
+    y = np.asarray(y)
+    H, W = y.shape[-2:]
+    cy, cx = H // 2 - 16, W // 2 - 16
+    y64 = y.astype(np.float64)
+    return dict(crop=y[..., cy:cy + 32, cx:cx + 32].copy(), grid=y[..., ::16, ::16].copy(),
+                corner=y[..., :16, :16].copy(), chsum=y64.sum(axis=(-2, -1)), chsq=(y64 * y64).sum(axis=(-2, -1)),
+                shape=np.asarray(y.shape, dtype=np.int64))
+
+
+def make_fullsize_input(name, shape):
+    import torch
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(("full_" + name).encode()) & 0x7FFFFFFF)
+    return torch.randn(shape, generator=g)
+
+
 SCHEDULES = {
     "sr3_2000": dict(schedule="linear", n_timestep=2000, linear_start=1e-6, linear_end=1e-2),
     "lin_8": dict(schedule="linear", n_timestep=8, linear_start=1e-4, linear_end=2e-1),

@@ -217,3 +217,51 @@ gt = torch.randn((3, 40, 56), generator=gp) * 2 + 1
 pred = 0.7 * gt + 0.3 * torch.randn((3, 40, 56), generator=gp) - 0.5
 save("psnr", gt=gt.numpy(), pred=pred.numpy(), psnr=PSNR(gt, pred).numpy(),
      ri_psnr=RangeInvariantPsnr(gt, pred).numpy())
+
+
+# ---------------------------------------------------------------- full-size cases (BASELINE C3 / C4 / C5 shapes)
+# Outputs are 512^2: the fixtures keep digests (cases.digest) of the reference's outputs.
+def save_digest(name, ks, y, **extra):
+    d = cases.digest(y)
+    save(name, keys=jstr(ks), **d, **extra)
+
+
+# C4: the sr_sr3_64_512 UNet, one forward, B = 1
+case = cases.FULLSIZE_CASES["c4_sr3_512"]
+net, ks = build_unet(case)
+x = cases.make_fullsize_input("c4_x", (1, 6, 512, 512))
+t = torch.tensor([[0.613]])
+save_digest("full_c4_unet", ks, net(x, t).numpy())
+del net
+
+# C3: the Hagen UNet, InDI.inference n = 3 on one 512^2 tile
+case = cases.FULLSIZE_CASES["c3_hagen_512"]
+net, ks = build_unet(case)
+indi = InDI(net, 32, channels=2, out_channel=2, conditional=False, val_schedule_opt={"n_timestep": 3}).eval()
+indi.set_new_noise_schedule({"n_timestep": 3}, "cpu")
+x_in = cases.make_fullsize_input("c3_x", (1, 1, 512, 512))
+torch.manual_seed(cases.LOOP_SEED)
+ret = indi.inference(x_in, continuous=True, t_float_start=1.0)
+save_digest("full_c3_indi", ks, ret.numpy())
+del net, indi
+
+# C5: JointIndi n = 3 on one 512^2 tile + the TimePredictor on two tiles
+case = cases.FULLSIZE_CASES["c5_joint_512"]
+n1 = UNetDdpm(**case["cfg"]).eval()
+n2 = UNetDdpm(**case["cfg"]).eval()
+joint = JointIndi(None, 32, channels=1, out_channel=1, denoise_fn_ch1=n1, denoise_fn_ch2=n2,
+                  conditional=False, val_schedule_opt={"n_timestep": 3}).eval()
+ks = key_shapes(joint)
+load_synth(joint, ks)
+joint.set_new_noise_schedule({"n_timestep": 3}, "cpu")
+x_in = cases.make_fullsize_input("c5_x", (1, 1, 512, 512))
+torch.manual_seed(cases.LOOP_SEED)
+ret = joint.inference(x_in, continuous=True, t_float_start=0.5)
+save_digest("full_c5_joint", ks, ret.numpy())
+del joint, n1, n2
+
+tp = TimePredictor(**case["cfg"]).eval()     # config/splitting_hagen_time_predictor.json: the same 1->1 UNet, no time embedding
+ks = key_shapes(tp)
+load_synth(tp, ks)
+x = cases.make_fullsize_input("c5_tp_x", (2, 1, 512, 512))
+save("full_c5_timepred", keys=jstr(ks), t=tp(x).numpy())

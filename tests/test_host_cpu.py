@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), name
     assert sorted(_lib.SIGNATURES) == declared
-    assert _lib.lib.dsx_abi_version() == 1
+    assert _lib.lib.dsx_abi_version() == 2
 
 
 def test_compute_fails_loudly_without_gpu():

@@ -147,3 +147,47 @@ def test_stitch_known_answer():
     assert plan.total() == 45
     preds = np.stack([tiling.extract_patch(data, plan, i) for i in range(plan.total())])
     assert (tiling.stitch(preds, plan) == data).all()
+
+
+# ----------------------------------------------------------------------------- full-size cases (C3 / C4 / C5 shapes)
+def _check_digest(y, g, atol):
+    d = cases.digest(y)
+    assert list(d["shape"]) == list(g["shape"])
+    for k in ("crop", "grid", "corner"):
+        np.testing.assert_allclose(d[k], g[k], rtol=0, atol=atol, err_msg=k)
+    npix = float(np.prod(d["shape"][-2:]))
+    np.testing.assert_allclose(d["chsum"] / npix, g["chsum"] / npix, rtol=0, atol=atol)
+    np.testing.assert_allclose(d["chsq"], g["chsq"], rtol=1e-4)
+
+
+def test_fullsize_c4_unet():
+    """The sr_sr3_64_512 UNet (config 4) at 512^2, B = 1: oracle vs the reference's digest."""
+    sd, g = golden_state_dict("full_c4_unet")
+    case = cases.FULLSIZE_CASES["c4_sr3_512"]
+    x = cases.make_fullsize_input("c4_x", (1, 6, 512, 512))
+    y = unet_forward(sd, case["cfg"], "sr3", x, torch.tensor([[0.613]]))
+    _check_digest(y.numpy(), g, 2e-4)
+
+
+def test_fullsize_c3_indi():
+    """InDI n = 3 on one 512^2 Hagen tile (config 3; bottleneck attention over 4096 tokens)."""
+    sd, g = golden_state_dict("full_c3_indi")
+    case = cases.FULLSIZE_CASES["c3_hagen_512"]
+    x_in = cases.make_fullsize_input("c3_x", (1, 1, 512, 512))
+    osd = {"denoise_fn." + k: v for k, v in sd.items()}
+    torch.manual_seed(cases.LOOP_SEED)
+    ret = samplers.indi_inference(osd, case["cfg"], x_in, 3, 2, continuous=True, t_float_start=1.0)
+    _check_digest(ret.numpy(), g, 2e-4)
+
+
+def test_fullsize_c5_joint_and_time_predictor():
+    sd, g = golden_state_dict("full_c5_joint")
+    case = cases.FULLSIZE_CASES["c5_joint_512"]
+    x_in = cases.make_fullsize_input("c5_x", (1, 1, 512, 512))
+    torch.manual_seed(cases.LOOP_SEED)
+    ret = samplers.joint_indi_inference(sd, case["cfg"], x_in, 3, 1, continuous=True, t_float_start=0.5)
+    _check_digest(ret.numpy(), g, 2e-4)
+    sd, g = golden_state_dict("full_c5_timepred")
+    x = cases.make_fullsize_input("c5_tp_x", (2, 1, 512, 512))
+    t = time_predictor_forward(sd, case["cfg"], x)
+    np.testing.assert_allclose(t.numpy(), g["t"], rtol=1e-5, atol=1e-6)

@@ -1,0 +1,97 @@
+"""Host-only checks of the launch planner (dsx_plan_dry_run: no GPU, no compute).
+
+Round 1 shipped a workspace overflow: the planner's sizing pass and its planning pass diverged for some tile
+preferences (a tiling decision keyed on a pointer that is null while sizing) and a conv wrote past the workspace
+(`Memory access fault`, DSX_MIN_GRID=448).  dsx_exec_create now fails unless both passes walk exactly the same
+number of bytes; these tests pin that for every tile-preference environment setting used while tuning, for all
+BASELINE configs and operand types.  Most knobs are read once per process, so every setting runs in a child."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (flavour, cfg kwargs, B, H, W, cond_channels)
+CONFIGS = {
+    "c2_sr3_128_b16": ("sr3", dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32,
+                                   channel_mults=(1, 2, 4, 8, 8), attn_res=(16,), res_blocks=2, image_size=128), 16, 128, 128, 3),
+    "c2_sr3_128_b1": ("sr3", dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=32,
+                                  channel_mults=(1, 2, 4, 8, 8), attn_res=(16,), res_blocks=2, image_size=128), 1, 128, 128, 3),
+    "c4_sr3_512_b2": ("sr3", dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=16,
+                                  channel_mults=(1, 2, 4, 8, 16), attn_res=(), res_blocks=1, image_size=512), 2, 512, 512, 3),
+    "c3_hagen_512_b8": ("ddpm", dict(in_channel=2, out_channel=2, inner_channel=16, norm_groups=16,
+                                     channel_mults=(1, 2, 4, 8), attn_res=(), res_blocks=1, image_size=32), 8, 512, 512, 0),
+    "c1_cifar_32_b4": ("ddpm", dict(in_channel=6, out_channel=6, inner_channel=16, norm_groups=16,
+                                    channel_mults=(1, 2, 4, 8), attn_res=(), res_blocks=1, image_size=32), 4, 32, 32, 0),
+    "ragged_48x80_b3": ("ddpm", dict(in_channel=2, out_channel=2, inner_channel=16, norm_groups=16,
+                                     channel_mults=(1, 2, 4), attn_res=(), res_blocks=1, image_size=32), 3, 48, 80, 0),
+}
+
+# the settings of the round-1 tuning sweeps (tools/tune.sh runs), the faulting one first
+ENV_SETS = [
+    {"DSX_MIN_GRID": "448"},
+    {},
+    {"DSX_MIN_GRID": "256"}, {"DSX_MIN_GRID": "384"}, {"DSX_MIN_GRID": "768"}, {"DSX_MIN_GRID": "1024"}, {"DSX_MIN_GRID": "2048"},
+    {"DSX_WS_MIN_GRID": "1"}, {"DSX_WS_MIN_GRID": "448"}, {"DSX_WS_MIN_GRID": "100000"},
+    {"DSX_WS": "0"}, {"DSX_SPLITK": "0"}, {"DSX_FUSE_STATS": "0"}, {"DSX_WS": "0", "DSX_SPLITK": "0", "DSX_FUSE_STATS": "0"},
+    {"DSX_TILES_WIDE": "1,2,5"}, {"DSX_TILES_WIDE": "0,1,2,5"}, {"DSX_TILES_WIDE": "2,5"}, {"DSX_TILES_NARROW": "4,5"},
+    {"DSX_TILES_NARROW": "3,4,5"}, {"DSX_TILES_WIDE_SPLIT": "1,2,5"}, {"DSX_TILES_NARROW_SPLIT": "4,5"},
+    {"DSX_TILES_WS_WIDE": "2"}, {"DSX_TILES_WS_WIDE": "2,1"}, {"DSX_TILES_WS_WIDE_1X1": "2"}, {"DSX_TILES_WS_NARROW": "5"},
+    {"DSX_TILES_WS_NARROW": "5,4"}, {"DSX_MIN_GRID": "448", "DSX_TILES_WIDE": "0,2,3,4"}, {"DSX_MIN_GRID": "448", "DSX_WS": "0"},
+]
+
+_CHILD = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r)
+from diffsplitting_amd import _lib     # ctypes only (no torch import: the child starts in ~0.1 s)
+configs = json.loads(sys.argv[1])
+out = {}
+for name, (flavour, kw, B, H, W, cc) in configs.items():
+    cfg = _lib.UnetCfg()
+    cfg.flavour = 0 if flavour == "sr3" else 1
+    for k in ("in_channel", "out_channel", "inner_channel", "norm_groups", "res_blocks", "image_size"):
+        setattr(cfg, k, kw[k])
+    cfg.n_mults = len(kw["channel_mults"]); cfg.n_attn_res = len(kw["attn_res"]); cfg.with_time_emb = 1
+    for i, m in enumerate(kw["channel_mults"]): cfg.channel_mults[i] = m
+    for i, m in enumerate(kw["attn_res"]): cfg.attn_res[i] = m
+    for dt, code in (("f32", 0), ("bf16", 1), ("f16", 2)):
+        a, b, n = C.c_size_t(), C.c_size_t(), C.c_int()
+        _lib.check(_lib.lib.dsx_plan_dry_run(C.byref(cfg), code, B, H, W, cc, C.byref(a), C.byref(b), C.byref(n)))
+        out[name + "/" + dt] = (a.value, b.value, n.value)
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("env", ENV_SETS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
+def test_sizing_and_planning_passes_agree(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _CHILD % ROOT, json.dumps(CONFIGS)], env=e, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(res) == 3 * len(CONFIGS)
+    for name, (sizing, planning, launches) in res.items():
+        assert sizing == planning and sizing > 0, (name, env, sizing, planning)
+        assert launches > 10
+
+
+def test_plan_rejects_sources_of_2gib():
+    """The conv kernels address a source with 32-bit byte offsets (0x80000000 = forced out of bounds): a tensor of
+    2 GiB or more must be refused by the planner, not silently read as zeros (sr_sr3_64_512 fp32 at B >= 16)."""
+    from diffsplitting_amd import engine
+    from diffsplitting_amd._lib import DsxError
+    flavour, kw, _, H, W, cc = CONFIGS["c4_sr3_512_b2"]
+    cfg = engine.make_cfg(flavour, kw["in_channel"], kw["out_channel"], kw["inner_channel"], kw["norm_groups"],
+                          kw["channel_mults"], kw["attn_res"], kw["res_blocks"], kw["image_size"])
+    a, b, _ = engine.plan_dry_run(cfg, "f32", 8, H, W, cc)          # 8 x 512 x 512 x 128 x 4 B = 1 GiB: fine
+    assert a == b
+    with pytest.raises(DsxError, match="2 GiB"):
+        engine.plan_dry_run(cfg, "f32", 16, H, W, cc)               # 16 x 512 x 512 x 128 x 4 B = 2 GiB
+    a, b, _ = engine.plan_dry_run(cfg, "bf16", 16, H, W, cc)        # bf16 storage halves it
+    assert a == b
+    with pytest.raises(DsxError, match="2 GiB"):
+        engine.plan_dry_run(cfg, "bf16", 32, H, W, cc)
