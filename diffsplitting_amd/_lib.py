@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsx.so")
+# DSX_LIB_PATH: diagnostic builds of the SAME library (tools/build_variant.sh: ablation / stamp builds) for
+# timing experiments; never a different implementation
+LIB_PATH = os.environ.get("DSX_LIB_PATH") or os.path.join(_HERE, "libdsx.so")
 
 
 class DsxError(RuntimeError):

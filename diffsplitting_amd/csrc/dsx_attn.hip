@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_a;
 namespace {
 
 template <class F, int... I>
-__device__ __forceinline__ void attn_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+__device__ __forceinline__ __attribute__((always_inline)) void attn_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);
 }
 template <int N, class F> __device__ __forceinline__ void attn_static_for(F&& f) {
@@ -80,7 +80,7 @@ __device__ __forceinline__ int vt_slot(int row, int slot) { return slot ^ (((row
 
 // NDB: 128-channel chunks of the (padded) head dimension
 template <int ST, int NDB>
-__global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
+__global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void k_attn(const AttnArgs a) {
   using T = AttnT<ST>;
   constexpr int ES = T::ES, DC = T::DC, VK = T::VK;
   constexpr bool F32 = ST == 0;
@@ -125,15 +125,17 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
   uint4 pre[10];                                      // the next unit, in flight: 8 K (or V) pieces + 2 Q pieces
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
-  auto ld16 = [&](const char* base, size_t row, int col_elem, int ncols_valid) -> uint4 {
+  auto ld16 = [&](const char* base, size_t row, int col_elem, int ncols_valid) __attribute__((always_inline)) -> uint4 {
     // 16 bytes = 16/ES elements starting at column col_elem of token `row`; columns >= C read as zero
     if (ncols_valid >= 16 / ES) return *(const uint4*)(base + row * ldb + (size_t)col_elem * ES);
     if (ncols_valid <= 0) return zero4;
     unsigned w[4] = {0u, 0u, 0u, 0u};
     if constexpr (F32) {
+#pragma unroll
       for (int e = 0; e < 4; ++e)
         if (e < ncols_valid) w[e] = *(const unsigned*)(base + row * ldb + (size_t)(col_elem + e) * 4);
     } else {
+#pragma unroll
       for (int e = 0; e < 8; ++e)
         if (e < ncols_valid) w[e >> 1] |= (unsigned)(*(const unsigned short*)(base + row * ldb + (size_t)(col_elem + e) * 2)) << (16 * (e & 1));
     }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
   };
 
   // unit ordinal u within a key tile: [0, KUNITS) K/Q units, [KUNITS, KUNITS + VUNITS) V units
-  auto issue_unit = [&](int key0, int u) {
+  auto issue_unit = [&](int key0, int u) __attribute__((always_inline)) {
     if (u < KUNITS) {
       const int c0 = u * DC + seg * (16 / ES);
 #pragma unroll
@@ -177,9 +179,9 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
       }
     }
   };
-  auto store_unit = [&](int u) {
+  auto store_unit = [&](int u) __attribute__((always_inline)) {
     if (u < KUNITS) {
-      auto put = [&](unsigned char* dst, const uint4 v) {
+      auto put = [&](unsigned char* dst, const uint4 v) __attribute__((always_inline)) {
         if constexpr (F32) {   // rows are 260 bytes apart (conflict-free one-float-per-lane reads): 4-byte stores
           unsigned* d = (unsigned*)dst;
           d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
     const int key0 = t * BK;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    attn_static_for<UPT>([&](auto uc) {
+    attn_static_for<UPT>([&](auto uc) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value;
       __syncthreads();                                // every wave is done with the previous unit's LDS image
       store_unit(u);

@@ -263,6 +263,7 @@ template <int N, class F> static __device__ __forceinline__ void static_for(F&& 
 template <int OFF> static __device__ __forceinline__ void lds_read_frag(f32x4_t& d, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
+static __device__ __forceinline__ void touch_frag(f32x4_t& d, unsigned addr) { asm volatile("" : "+v"(d) : "v"(addr)); }
 template <int N> static __device__ __forceinline__ void wait_frags(f32x4_t& a) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
 }
@@ -935,6 +936,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
           Unit<DT>::unpack(__builtin_bit_cast(uint4, rv[it]), v);
           // the arithmetic runs in every lane; padding pixels (and channels past C) are forced to exactly 0
           // afterwards with one mask per packed register (padded AFTER the activation, as the reference does)
+#ifndef DSX_ABL_CVT   // -DDSX_ABL_CVT: timing experiment, loaders skip the GroupNorm / Swish arithmetic (results wrong)
           if (gnF) {
 #pragma unroll
             for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
@@ -943,6 +945,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #pragma unroll
             for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
           }
+#endif
           if (it == NIT - 1) { asm volatile("" :: "v"(v[0]), "v"(v[CPU - 1])); DSX_STAMP_T(122, tid == 256 && tiC == 2 && gC == 0); }
           uint4 w = Unit<DT>::pack(v);
           const unsigned keep = ((edge[it] & flagsF) == 0 && cF < C) ? 0xffffffffu : 0u;
@@ -1164,8 +1167,13 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       constexpr int dy = tap / KS, dx = tap % KS;
       constexpr int imm = dx * PIXB + cg * 64 + fs * 32;
       static_assert(imm < 65536, "ds offset field");
+#ifndef DSX_ABL_L   // -DDSX_ABL_L: timing experiment, LDS operand reads off (results wrong)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) lds_read_frag<imm>(fb[s % (PF + 1)][mb], aaddr[mb][dy]);
+#else
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) touch_frag(fb[s % (PF + 1)][mb], aaddr[mb][dy]);
+#endif
     };
     static_for<PF>(read_step);
     static_for<NSTEP>([&](auto sc) {
@@ -1246,7 +1254,9 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         float x[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = acc[mb][nb][r];
+#ifndef DSX_ABL_EPI   // -DDSX_ABL_EPI: timing experiment, no output stores (results wrong)
         store16<true>(a.out, (size_t)(o0 + orow[mb] + 32 * nb), x, Kind<DT>::value, 16);   // host: out is in the storage type
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s1[r] += x[r]; s2[r] += x[r] * x[r]; }
 #pragma unroll
