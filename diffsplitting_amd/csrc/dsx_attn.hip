@@ -80,7 +80,7 @@ __device__ __forceinline__ int vt_slot(int row, int slot) { return slot ^ (((row
 
 // NDB: 128-channel chunks of the (padded) head dimension
 template <int ST, int NDB>
-__global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void k_attn(const AttnArgs a) {
+__global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs a) {
   using T = AttnT<ST>;
   constexpr int ES = T::ES, DC = T::DC, VK = T::VK;
   constexpr bool F32 = ST == 0;
@@ -113,48 +113,41 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void k_attn(const AttnArgs
   const int b = j / QT, q0 = (j - b * QT) * BQ;
 
   const size_t row0 = (size_t)b * a.L;                // first token row of the image in the qkv tensor
-  const char* qbase = (const char*)a.q;
-  const char* kbase = (const char*)a.k;
-  const char* vbase = (const char*)a.v;
   const size_t ldb = (size_t)a.ld * ES;               // bytes per token row
 
   // ---- staging plans.  Global reads: 16 lanes x 16 B = one 256-byte row segment per 16 lanes.
   constexpr int SEGS = (DC * ES) / 16;                // 16-byte segments per K/Q unit row (16)
   static_assert(SEGS == 16, "a staged K/Q row is 256 bytes");
   const int seg = tid & 15, rsub = tid >> 4;          // rsub: 0..15
-  uint4 pre[10];                                      // the next unit, in flight: 8 K (or V) pieces + 2 Q pieces
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  constexpr int PD = 2;                               // staged units in flight (global -> registers)
+  uint4 pre[PD][10];                                  // 8 K (or V) pieces + 2 Q pieces each
 
-  auto ld16 = [&](const char* base, size_t row, int col_elem, int ncols_valid) __attribute__((always_inline)) -> uint4 {
-    // 16 bytes = 16/ES elements starting at column col_elem of token `row`; columns >= C read as zero
-    if (ncols_valid >= 16 / ES) return *(const uint4*)(base + row * ldb + (size_t)col_elem * ES);
-    if (ncols_valid <= 0) return zero4;
-    unsigned w[4] = {0u, 0u, 0u, 0u};
-    if constexpr (F32) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (e < ncols_valid) w[e] = *(const unsigned*)(base + row * ldb + (size_t)(col_elem + e) * 4);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (e < ncols_valid) w[e >> 1] |= (unsigned)(*(const unsigned short*)(base + row * ldb + (size_t)(col_elem + e) * 2)) << (16 * (e & 1));
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+  // Every load goes through one buffer descriptor over this image's L token rows (q, k and v are column ranges of
+  // the same rows): rows past L fall outside the descriptor and read as zero, columns past C get the forced
+  // out-of-range offset -> no predicate, no branch, no wait around any load (a per-load "load or zero" branch makes
+  // hipcc serialise the loads behind vmcnt(0) waits).
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)a.q + row0 * ldb), 0, (int)((size_t)a.L * ldb), 0x00020000);
+  const unsigned koff = (unsigned)((const char*)a.k - (const char*)a.q), voff = (unsigned)((const char*)a.v - (const char*)a.q);
+  auto ld16 = [&](unsigned tensor_off, int row, int col_elem) __attribute__((always_inline)) -> uint4 {
+    // 16 bytes = 16/ES elements at column col_elem of token `row` of the image (host: C is a multiple of 16/ES)
+    const unsigned vo = col_elem < a.C ? (unsigned)row * (unsigned)ldb + tensor_off + (unsigned)col_elem * ES : 0x80000000u;
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
   };
 
   // unit ordinal u within a key tile: [0, KUNITS) K/Q units, [KUNITS, KUNITS + VUNITS) V units
-  auto issue_unit = [&](int key0, int u) __attribute__((always_inline)) {
+  auto issue_unit = [&](int key0, int u, uint4 (&pre)[10]) __attribute__((always_inline)) {
     if (u < KUNITS) {
       const int c0 = u * DC + seg * (16 / ES);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int key = key0 + rsub + 16 * it;
-        pre[it] = key < a.L ? ld16(kbase, row0 + key, c0, a.C - c0) : zero4;
+        pre[it] = ld16(koff, key, c0);
       }
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int q = q0 + rsub + 16 * it;
-        pre[8 + it] = q < a.L ? ld16(qbase, row0 + q, c0, a.C - c0) : zero4;
+        pre[8 + it] = ld16(0u, q, c0);
       }
     } else {
       const int v = u - KUNITS, chunk = v / VPC, part = v - chunk * VPC;
@@ -165,7 +158,7 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void k_attn(const AttnArgs
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
           const int key = key0 + part * VK + r8 + 8 * it;
-          pre[it] = key < a.L ? ld16(vbase, row0 + key, c0, a.C - c0) : zero4;
+          pre[it] = ld16(voff, key, c0);
         }
       } else {
         // key pairs (2i, 2i+1) x 16-byte channel segment: thread -> (segment tid%16, pair tid/16 + 16*it)
@@ -173,13 +166,13 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void k_attn(const AttnArgs
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int key = key0 + 2 * (rsub + 16 * it);
-          pre[2 * it] = key < a.L ? ld16(vbase, row0 + key, c0, a.C - c0) : zero4;
-          pre[2 * it + 1] = key + 1 < a.L ? ld16(vbase, row0 + key + 1, c0, a.C - c0) : zero4;
+          pre[2 * it] = ld16(voff, key, c0);
+          pre[2 * it + 1] = ld16(voff, key + 1, c0);
         }
       }
     }
   };
-  auto store_unit = [&](int u) __attribute__((always_inline)) {
+  auto store_unit = [&](int u, const uint4 (&pre)[10]) __attribute__((always_inline)) {
     if (u < KUNITS) {
       auto put = [&](unsigned char* dst, const uint4 v) __attribute__((always_inline)) {
         if constexpr (F32) {   // rows are 260 bytes apart (conflict-free one-float-per-lane reads): 4-byte stores
@@ -226,7 +219,9 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void k_attn(const AttnArgs
 
   const int ntiles = (a.L + BK - 1) / BK;
   constexpr int UPT = KUNITS + VUNITS;
-  issue_unit(0, 0);
+  static_assert(UPT % PD == 0 && UPT >= PD, "the register slot of a unit is a compile-time constant");
+  issue_unit(0, 0, pre[0]);
+  issue_unit(0, 1, pre[1]);
   for (int t = 0; t < ntiles; ++t) {
     const int key0 = t * BK;
 #pragma unroll
@@ -234,12 +229,12 @@ __global__ __launch_bounds__(256, (NDB <= 4 ? 2 : 1)) void k_attn(const AttnArgs
     attn_static_for<UPT>([&](auto uc) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value;
       __syncthreads();                                // every wave is done with the previous unit's LDS image
-      store_unit(u);
+      store_unit(u, pre[u % PD]);
       __syncthreads();
-      {                                               // next unit's global loads fly during this unit's MFMAs
-        constexpr int nu = (u + 1 == UPT) ? 0 : u + 1;
-        const int nk = (u + 1 == UPT) ? key0 + BK : key0;
-        if (nk < a.L) issue_unit(nk, nu);
+      {                                               // the loads of unit u + PD fly during the MFMAs of u .. u + PD - 1
+        constexpr int nu = (u + PD) % UPT;
+        const int nk = (u + PD >= UPT) ? key0 + BK : key0;
+        if (nk < a.L) issue_unit(nk, nu, pre[u % PD]);
       }
       if constexpr (u < KUNITS) {
         // ---- S^T[key][query] += K[key][d] . Q[query][d] over this unit's DC columns
@@ -378,7 +373,7 @@ template <int ST> hipError_t launch_attn_st(const AttnArgs& a, hipStream_t st) {
 }
 }  // namespace
 
-bool attn_supported(int C, int L) { return C >= 4 && C <= 1024 && (C & 3) == 0 && L >= 1; }
+bool attn_supported(int C, int L) { return C >= 8 && C <= 1024 && (C & 7) == 0 && L >= 1 && (long long)L * 3 * C * 4 < (1LL << 31); }
 
 hipError_t launch_attn(const AttnArgs& a, hipStream_t st) {
   if (!attn_supported(a.C, a.L) || a.B < 1) return hipErrorInvalidValue;

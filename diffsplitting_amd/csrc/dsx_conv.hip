@@ -26,6 +26,7 @@
 //                  holds one pixel x 16 consecutive channels -> 16-byte loads / NHWC stores only.
 #include "dsx_kernels.h"
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -1281,6 +1282,316 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   }
 }
 
+
+// ===========================================================================================
+// Image-resident kernel for the 8 x 8 feature maps (the bottleneck level of sr_sr3_16_128: 512 / 1024 channels).
+//
+// Why: with M = 64 pixels per image a tile grid cannot fill the chip, so the tiled kernels split K over
+// workgroups (fp32 slabs through HBM + a reduce launch: 16.8 MB of slab traffic for a 4.7 MB weight tensor) and
+// every GroupNorm costs a k_gn_finalize launch: ~32 us per layer for ~2 us of MFMA work.  Here one workgroup
+// (8 waves) owns one image x one 32-channel N block and the WHOLE K extent:
+//   * K is split over the 8 waves: in phase p wave w owns the 64-byte channel chunk 8p + w for all taps; its
+//     slice of the (zero-bordered) halo image lives in a wave-private LDS buffer, so the main loop has no
+//     workgroup barrier at all;
+//   * GroupNorm is finalised here: lanes = channels, the producer's partial sums are reduced over the group with
+//     wave shuffles (double, fixed order), affine + Swish are applied while the slice is written to LDS;
+//   * weights stream from L2 in MFMA fragment order straight into registers (ring of D fragments);
+//   * the 8 partial accumulators meet in LDS (fixed order -> bitwise reproducible), the epilogue adds bias / FiLM /
+//     residual, stores, and emits the complete per-(image, channel) GroupNorm sums of the result (one partial row).
+// ===========================================================================================
+template <typename DT, int KS>
+__global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
+  constexpr int KC = Chunk<DT>::KC;
+  constexpr int CPU = Unit<DT>::N;
+  constexpr int ES = (int)sizeof(DT);
+  constexpr int TAPS = KS * KS, PAD = KS / 2, PW = 8 + 2 * PAD;
+  constexpr int PIXB = 80;
+  constexpr int RB = KS == 3 ? 896 : 640;       // conv_lds_row(KS, 1, 3): conflict-free ds_read_b128 of 8-wide rows
+  constexpr int IMGB = PW * RB;
+  constexpr int NSTEP = TAPS * 2;
+  constexpr int D = NSTEP;                      // weight fragments in flight: a whole phase (latency, not bandwidth, bounds the stream)
+  constexpr int MAXP = 8;                       // phases (host: C <= 8 * 8 * KC)
+  static_assert(NSTEP % D == 0, "ring depth divides the steps of a phase");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int nb = blockIdx.x % a.nblocks, b = blockIdx.x / a.nblocks;
+  const int C = a.C0 + a.C1;
+  const int nphase = C / (8 * KC);
+  unsigned char* img = lds + wave * (2 * IMGB);
+  float* aff = (float*)(lds + 8 * 2 * IMGB) + wave * (MAXP * 2 * KC);   // [phase][scale KC | shift KC]
+
+  DSX_STAMP(0);
+  // zero both buffers once: the halo border stays zero (the reference pads AFTER the activation)
+  if (KS == 3) {
+    // 36 border pixels x 5 sixteen-byte units x 2 buffers = 360 units: top / bottom rows, left / right columns
+    for (int q = lane; q < 360; q += 64) {
+      const int bufi = q >= 180, r = q - 180 * bufi, bp = r / 5, u = r - 5 * bp;
+      int py, px2;
+      if (bp < 10) { py = 0; px2 = bp; }
+      else if (bp < 20) { py = 9; px2 = bp - 10; }
+      else { py = 1 + ((bp - 20) >> 1); px2 = ((bp - 20) & 1) ? 9 : 0; }
+      *(uint4*)(img + bufi * IMGB + py * RB + px2 * PIXB + u * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+
+  // ---- this wave's slice of phase p: 64 pixels x one 64-byte chunk = 4 staging units per lane
+  auto load_raw = [&](int p, uint4 (&raw)[4]) __attribute__((always_inline)) {
+    const int c0 = (p * 8 + wave) * KC;
+    const bool first = c0 < a.C0;
+    const char* src = (const char*)(first ? a.src0 : a.src1);
+    const int Cs = first ? a.C0 : a.C1, cl = first ? c0 : c0 - a.C0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = lane + 64 * i, px = q >> 2, u = q & 3;
+      raw[i] = *(const uint4*)(src + (((size_t)b * 64 + px) * Cs + cl + u * CPU) * ES);
+    }
+  };
+  auto convert_store = [&](int p, const uint4 (&raw)[4]) __attribute__((always_inline)) {
+    unsigned char* buf = img + (p & 1) * IMGB;
+    const int u = lane & 3;
+    float sc[CPU], sh[CPU];
+    if (a.has_gn) {
+#pragma unroll
+      for (int j = 0; j < CPU; ++j) { sc[j] = aff[p * 2 * KC + u * CPU + j]; sh[j] = aff[p * 2 * KC + KC + u * CPU + j]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = (lane + 64 * i) >> 2;
+      float v[CPU];
+      Unit<DT>::unpack(raw[i], v);
+      if (a.has_gn) {
+#pragma unroll
+        for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
+      }
+      if (a.swish) {
+#pragma unroll
+        for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
+      }
+      *(uint4*)(buf + ((px >> 3) + PAD) * RB + ((px & 7) + PAD) * PIXB + u * 16) = Unit<DT>::pack(v);
+    }
+  };
+
+  uint4 raw0[4], raw1[4];
+  load_raw(0, raw0);
+  if (nphase > 1) load_raw(1, raw1);
+
+  // ---- weight stream: fragments of (N block nb, chunk 8p + wave), NSTEP x 1 KiB per phase, flat over the phases
+  const unsigned char* wbase = (const unsigned char*)a.wpack + (size_t)nb * a.kchunks * (NSTEP * 1024) + lane * 16;
+  int pn = 0, sn = 0;                           // phase and step of the next fragment to prefetch
+  auto load_w = [&]() __attribute__((always_inline)) -> uint4 {   // unconditional: the caller stops at the last phase
+    const uint4 v = *(const uint4*)(wbase + ((size_t)(pn * 8 + wave) * NSTEP + sn) * 1024);
+    if (++sn == NSTEP) { sn = 0; ++pn; }
+    return v;
+  };
+  uint4 wq[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) wq[j] = load_w();
+  DSX_STAMP(1);
+
+  // ---- GroupNorm: scale / shift of this wave's channels of every phase (lanes = 64 consecutive channels).
+  // All loads of all phases are issued before the first use (one memory round trip, not one per phase).
+  if (a.has_gn) {
+    const int cpg = C / a.gn_groups;            // host: power of two <= 64, divides C0
+    // branch-free loads (a "load or skip" branch per phase would make hipcc wait vmcnt(0) inside every branch):
+    // phases past the last re-read the last one, the element is fetched as two 8-byte halves for either partial type
+    uint2 glo[MAXP], ghi[MAXP];
+    float gg[MAXP], gb[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int pp = p < nphase ? p : nphase - 1;
+      const int c0 = (pp * 8 + wave) * KC, cb = c0 & ~63, c = cb + lane;   // c < C: C0, C1 are multiples of 64
+      const bool first = cb < a.C0;             // wave-uniform
+      const char* part = (const char*)(first ? a.gn_part0 : a.gn_part1);
+      const int nch = first ? a.gn_nchunk0 : a.gn_nchunk1, pf32 = first ? a.gn_pf32_0 : a.gn_pf32_1;
+      const int Cs = first ? a.C0 : a.C1, cl = first ? c : c - a.C0;
+      const char* e = part + (((size_t)b * nch) * Cs + cl) * (pf32 ? 8 : 16);
+      glo[p] = *(const uint2*)e;
+      ghi[p] = *(const uint2*)(e + 8);          // second half of a double2 (ignored for float partials; stays inside the workspace)
+      gg[p] = a.gn_gamma[c]; gb[p] = a.gn_beta[c];
+    }
+    double gs[MAXP], gq[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int pp = p < nphase ? p : nphase - 1;
+      const int cb = ((pp * 8 + wave) * KC) & ~63, c = cb + lane;
+      const bool first = cb < a.C0;
+      const int nch = first ? a.gn_nchunk0 : a.gn_nchunk1, pf32 = first ? a.gn_pf32_0 : a.gn_pf32_1;
+      const double d0 = __builtin_bit_cast(double, ((unsigned long long)glo[p].y << 32) | glo[p].x);
+      const double d1 = __builtin_bit_cast(double, ((unsigned long long)ghi[p].y << 32) | ghi[p].x);
+      gs[p] = pf32 ? (double)__builtin_bit_cast(float, glo[p].x) : d0;
+      gq[p] = pf32 ? (double)__builtin_bit_cast(float, glo[p].y) : d1;
+      if (nch > 1 && p < nphase) {              // producers with several partial rows (split-K reduce, k_chan_stats): rare
+        const char* part = (const char*)(first ? a.gn_part0 : a.gn_part1);
+        const int Cs = first ? a.C0 : a.C1, cl = first ? c : c - a.C0;
+        for (int k = 1; k < nch; ++k) {
+          const size_t idx = (((size_t)b * nch + k) * Cs + cl) * 2;
+          if (pf32) { const float2 v = *(const float2*)((const float*)part + idx); gs[p] += v.x; gq[p] += v.y; }
+          else { const double2 v = *(const double2*)((const double*)part + idx); gs[p] += v.x; gq[p] += v.y; }
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      if (p < nphase) {
+        const int c0 = (p * 8 + wave) * KC, c = (c0 & ~63) + lane;
+        double s = gs[p], q = gq[p];
+        for (int o = 1; o < cpg; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        const double n = 64.0 * cpg;            // H * W elements per channel
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+        const float meanf = (float)mean;
+        if (c >= c0 && c < c0 + KC) {
+          const float sc = rstd * gg[p];
+          aff[p * 2 * KC + (c - c0)] = sc;
+          aff[p * 2 * KC + KC + (c - c0)] = gb[p] - meanf * sc;
+        }
+      }
+    }
+  }
+  DSX_STAMP(2);
+  __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): the zero fill and the aff table are in LDS
+  convert_store(0, raw0);
+  if (nphase > 1) convert_store(1, raw1);
+  DSX_STAMP(3);
+
+  int abase[2][KS];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = mb * 32 + li;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) abase[mb][dy] = ((m >> 3) + dy) * RB + (m & 7) * PIXB + lh * 16;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+  for (int p = 0; p < nphase; ++p) {
+    const unsigned char* buf = img + (p & 1) * IMGB;
+    if (p + 2 < nphase) load_raw(p + 2, raw0);   // in flight during this phase's MFMAs
+    const bool more = p + 1 < nphase;
+    static_for<NSTEP>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int tap = s >> 1, fs = s & 1, dy = tap / KS, dx = tap % KS;
+      const uint4 wcur = wq[s % D];
+      if (more) wq[s % D] = load_w();            // uniform: the next phase's fragment into the slot just consumed
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const f32x4_t px = *(const f32x4_t*)(buf + abase[mb][dy] + dx * PIXB + fs * 32);
+        acc[mb] = mfma_step<DT>(wcur, px, acc[mb]);
+      }
+    });
+    if (p + 2 < nphase) convert_store(p + 2, raw0);   // refill this buffer with the slice of phase p + 2
+    DSX_STAMP(4 + p);
+  }
+
+  // ---- the 8 partial sums meet in LDS: part[w][mb][r][lane]
+  __syncthreads();
+  DSX_STAMP(12);
+  float* part = (float*)lds;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)   // [w][mb][lane][16 registers], 80-byte lane stride: conflict-free 16-byte accesses
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *(float4*)(part + ((wave * 2 + mb) * 64 + lane) * 20 + 4 * j) =
+          make_float4(acc[mb][4 * j], acc[mb][4 * j + 1], acc[mb][4 * j + 2], acc[mb][4 * j + 3]);
+  __syncthreads();
+  DSX_STAMP(13);
+  // thread -> pixel tid >> 3, channels 4 * (tid & 7) .. + 3 of the block.  Accumulator register r of lane
+  // (li, lh) of block mb is pixel 32 mb + li, channel 16 lh + r.
+  const int px = tid >> 3, cg = (tid & 7) * 4;
+  const int mbo = px >> 5, lo = (px & 31) + 32 * (cg >> 4), r0 = cg & 15;
+  float x[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const float4 t = *(const float4*)(part + ((w * 2 + mbo) * 64 + lo) * 20 + r0);
+    x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w;
+  }
+  const int n0 = nb * 32 + cg;
+  const size_t opix = (size_t)b * 64 + px;
+  if (a.bias) { const float4 t = *(const float4*)(a.bias + n0); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
+  if (a.film) { const float4 t = *(const float4*)(a.film + (size_t)b * a.film_bs + n0); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
+  if (a.resid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] += act_load<DT>(a.resid, opix * a.resid_ld + n0 + j);
+  }
+  const int okind = a.out_bf16;
+  if (okind == 0) {
+    *(float4*)((float*)a.out + opix * a.out_ld + n0) = make_float4(x[0], x[1], x[2], x[3]);
+  } else {
+    uint2 w2;
+    if (okind == 1) { w2.x = pack_bf16x2(x[0], x[1]); w2.y = pack_bf16x2(x[2], x[3]); }
+    else { w2.x = pack_f16x2(x[0], x[1]); w2.y = pack_f16x2(x[2], x[3]); }
+    *(uint2*)((unsigned short*)a.out + opix * a.out_ld + n0) = w2;
+  }
+  DSX_STAMP(14);
+  // ---- GroupNorm sums of the result over the image's 64 pixels (complete: one partial row per image)
+  if (a.stat_part != nullptr) {
+    float s1[4], s2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = x[j]; s2[j] = x[j] * x[j]; }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    __syncthreads();                             // `part` is read; reuse its first bytes
+    float* red = (float*)lds;                    // [8 waves][32 channels][2]
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[(wave * 32 + cg + j) * 2] = s1[j]; red[(wave * 32 + cg + j) * 2 + 1] = s2[j]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int ch = tid >> 1, k = tid & 1;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[(w * 32 + ch) * 2 + k];
+      a.stat_part[((size_t)b * a.Cout + nb * 32 + ch) * 2 + k] = t;
+    }
+  }
+  DSX_STAMP(15);
+}
+
+static size_t conv_img_lds(int dtype, int ks) {
+  const int KC = dtype != 0 ? 32 : 16;
+  const int pw = ks == 3 ? 10 : 8, rb = ks == 3 ? 896 : 640;
+  return (size_t)8 * 2 * pw * rb + (size_t)8 * 8 * 2 * KC * sizeof(float);
+}
+bool conv_img_applicable(int dtype, int ks, int stride, const ConvArgs& a, bool gn, int gn_groups) {
+  static const int on = getenv("DSX_IMG") ? atoi(getenv("DSX_IMG")) : 1;
+  if (!on || stride != 1 || a.up || !(ks == 1 || ks == 3)) return false;
+  if (a.Hs != 8 || a.Ws != 8 || a.Ho != 8 || a.Wo != 8) return false;
+  const int KC = dtype != 0 ? 32 : 16, C = a.C0 + a.C1;
+  if (a.C0 % (8 * KC) || a.C1 % (8 * KC) || C / (8 * KC) > 8 || C < 8 * KC) return false;
+  if (a.Cout % 32 || (a.out_ld & 3) || (a.resid && (a.resid_ld & 3))) return false;
+  if (gn) {
+    if (gn_groups < 1 || C % gn_groups) return false;
+    const int cpg = C / gn_groups;
+    if (cpg > 64 || (cpg & (cpg - 1)) || a.C0 % cpg) return false;
+  }
+  return true;
+}
+template <typename DT, int KS> static hipError_t launch_img_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
+  auto kern = k_conv_img<DT, KS>;
+  if (!ap) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ap->B * ap->nblocks)), dim3(512), lds, st, *ap);
+  return hipGetLastError();
+}
+template <typename DT> static hipError_t launch_img_dt(int ks, const ConvArgs* a, size_t lds, hipStream_t st) {
+  return ks == 3 ? launch_img_one<DT, 3>(a, lds, st) : launch_img_one<DT, 1>(a, lds, st);
+}
+hipError_t launch_conv_img(int dtype, int ks, const ConvArgs& a, hipStream_t st) {
+  const size_t lds = conv_img_lds(dtype, ks);
+  return dtype == 1 ? launch_img_dt<__bf16>(ks, &a, lds, st)
+       : dtype == 2 ? launch_img_dt<_Float16>(ks, &a, lds, st) : launch_img_dt<float>(ks, &a, lds, st);
+}
+
 // ------------------------------------------------------------------ dispatch
 struct TileCfg { int MB, WM, WN; };
 static constexpr TileCfg kTiles[TILE_COUNT] = {
@@ -1502,6 +1813,12 @@ hipError_t conv_init() {
             if (e != hipSuccess) return e;
           }
         }
+  for (int ks = 1; ks <= 3; ks += 2) {
+    hipError_t e = launch_img_dt<float>(ks, nullptr, 0, nullptr);
+    if (e == hipSuccess) e = launch_img_dt<__bf16>(ks, nullptr, 0, nullptr);
+    if (e == hipSuccess) e = launch_img_dt<_Float16>(ks, nullptr, 0, nullptr);
+    if (e != hipSuccess) return e;
+  }
   done = true;
   return hipSuccess;
 }

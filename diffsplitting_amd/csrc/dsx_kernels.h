@@ -49,6 +49,12 @@ struct ConvArgs {
   unsigned long long* stamp;  // diagnostic s_memtime stamps of workgroup `stamp_block` (or nullptr)
   int stamp_block;
   int ablate;             // -DDSX_DIAG builds only: DSX_ABLATE timing experiments (results are wrong when non-zero)
+  // k_conv_img only (GroupNorm finalised inside the consumer): the partial sums of the sources as their producers
+  // left them ([B][nchunk][C][2], double from k_chan_stats or float from a fused epilogue) and the affine parameters
+  const void* gn_part0; int gn_nchunk0, gn_pf32_0;
+  const void* gn_part1; int gn_nchunk1, gn_pf32_1;
+  const float* gn_gamma; const float* gn_beta;
+  int gn_groups; float gn_eps;
   int ksplit;             // split-K slices (1 = none); slice s writes raw sums to out + s*slab_stride
   int groups_per_split;   // channel groups per slice
   long long slab_stride;  // elements between slabs
@@ -71,6 +77,11 @@ hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& 
 // warp-specialised persistent variant (stride 1, stage_mode 0, no split-K); 0 bytes = not applicable
 size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a);
 hipError_t launch_conv_ws(int dtype, int tile, int ks, const ConvArgs& a, hipStream_t st);
+// image-resident kernel for 8 x 8 feature maps (one workgroup = one image x 32 output channels, the whole K inside
+// the workgroup, GroupNorm finalised in the prologue, statistics of the result in the epilogue): no split-K slabs,
+// no reduce launch, no k_gn_finalize launch.  `gn` says whether a GroupNorm precedes the conv.
+bool conv_img_applicable(int dtype, int ks, int stride, const ConvArgs& a, bool gn, int gn_groups);
+hipError_t launch_conv_img(int dtype, int ks, const ConvArgs& a, hipStream_t st);
 // one-time function attributes (dynamic LDS limit); call outside any stream capture
 hipError_t conv_init();
 hipError_t ops_init();

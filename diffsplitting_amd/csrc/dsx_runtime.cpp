@@ -689,8 +689,8 @@ struct ConvSpec {
   Tensor x0, x1;       // x1.p == nullptr / C == 0: single source
   bool up = false;
   int stride = 1;
-  const float* gn_scale = nullptr; const float* gn_shift = nullptr;
-  bool has_gn = false;       // set by the planner, not derived from pointers (null during the sizing pass)
+  const GnW* gn = nullptr;   // GroupNorm over cat(x0, x1) in front of the conv (finalised by k_gn_finalize, or inside
+                             // the consumer by k_conv_img)
   bool has_resid = false;
   bool swish = false;
   const float* film = nullptr; int film_bs = 0;
@@ -700,14 +700,17 @@ struct ConvSpec {
   bool bias_in_film = false; // the conv bias is already part of the FiLM vector (dsx_model_finalize)
 };
 
+static void plan_stats(dsx_exec* ex, const Tensor& t);
+static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* t1, float** scale, float** shift);
+
 static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   ConvArgs a{};
   a.src0 = s.x0.p; a.C0 = s.x0.C;
   a.src1 = s.x1.C ? s.x1.p : nullptr; a.C1 = s.x1.C;
   a.B = ex->B; a.Hs = s.x0.H; a.Ws = s.x0.W; a.up = s.up ? 1 : 0;
   a.Ho = s.out.H; a.Wo = s.out.W;
-  a.gn_scale = s.gn_scale; a.gn_shift = s.gn_shift; a.swish = s.swish ? 1 : 0;
-  a.has_gn = s.has_gn ? 1 : 0;
+  a.swish = s.swish ? 1 : 0;
+  a.has_gn = s.gn ? 1 : 0;
   a.act_bf16 = ex->m->dtype;   // storage kind of the sources / residual
   a.out_bf16 = s.out.st;
   {
@@ -732,6 +735,58 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
                   "use a smaller batch per executor", src_bytes, a.B, a.Hs, a.Ws, std::max(a.C0, a.C1));
   }
   const int dtype = ex->m->dtype, ks = s.w->ks, stride = s.stride;
+  const double npix = (double)a.B * a.Ho * a.Wo;
+  const double cin = a.C0 + a.C1;
+  const double flops = 2.0 * npix * a.Cout * cin * ks * ks;
+  const double wbytes = (double)a.Cout * cin * ks * ks * (dtype != 0 ? 2 : 4);
+  const double esz = dtype != 0 ? 2.0 : 4.0;   // activation element size in HBM
+  const double bytes = esz * ((double)a.B * a.Hs * a.Ws * cin + npix * a.Cout * (s.has_resid || s.resid ? 1 : 0)) +
+                       (a.out_bf16 ? 2.0 : 4.0) * npix * a.Cout + wbytes;
+  {  // diagnostics: DSX_STAMP_OP=<conv ordinal>[,<block>] -> in-kernel phase stamps of that launch
+    static const char* se = getenv("DSX_STAMP_OP");
+    if (se) {
+      const int want = atoi(se);
+      const char* comma = strchr(se, ',');
+      if (ex->conv_ordinal == want) {
+        a.stamp = (unsigned long long*)ws_alloc(ex, 128 * 8);
+        a.stamp_block = comma ? atoi(comma + 1) : 0;
+        ex->stamp_buf = a.stamp;
+      }
+    }
+    ex->conv_ordinal++;
+  }
+  // ---- 8 x 8 maps: the image-resident kernel (GroupNorm finalised in its prologue, statistics in its epilogue)
+  if (!ex->m->want_naive && conv_img_applicable(dtype, ks, stride, a, s.gn != nullptr, ex->m->cfg.norm_groups)) {
+    ex->launches++;
+    if (s.gn) {
+      plan_stats(ex, s.x0);
+      if (s.x1.C) plan_stats(ex, s.x1);
+      const StatInfo& s0 = ex->stats[s.x0.id];
+      a.gn_part0 = s0.part; a.gn_nchunk0 = s0.nchunk; a.gn_pf32_0 = s0.f32 ? 1 : 0;
+      if (s.x1.C) {
+        const StatInfo& s1 = ex->stats[s.x1.id];
+        a.gn_part1 = s1.part; a.gn_nchunk1 = s1.nchunk; a.gn_pf32_1 = s1.f32 ? 1 : 0;
+      }
+      a.gn_gamma = s.gn->gamma; a.gn_beta = s.gn->beta; a.gn_groups = ex->m->cfg.norm_groups; a.gn_eps = 1e-5f;
+    }
+    if (s.want_stats) {
+      StatInfo& si = ex->stats[s.out.id];
+      si.nchunk = 1;
+      si.part = ws_alloc(ex, (size_t)a.B * a.Cout * 2 * sizeof(float));
+      si.planned = true;
+      si.f32 = true;
+      a.stat_part = (float*)si.part;
+    }
+    if (ex->sizing) return DSX_OK;
+    add_op(ex, DSX_OP_CONV_MFMA, fmt("conv%dx%d %d->%d @%dx%d img", ks, ks, (int)cin, a.Cout, a.Ho, a.Wo), flops, bytes,
+           [=](hipStream_t st) { return launch_conv_img(dtype, ks, a, st); });
+    return DSX_OK;
+  }
+  if (s.gn) {   // every other kernel takes the per-channel scale / shift a k_gn_finalize launch prepares
+    float *sc = nullptr, *sh = nullptr;
+    plan_gn(ex, *s.gn, s.x0, s.x1.C ? &s.x1 : nullptr, &sc, &sh);
+    a.gn_scale = sc; a.gn_shift = sh;
+  }
   int tile = -1;
   const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
   ex->launches++;
@@ -750,19 +805,6 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
     si.f32 = true;
     a.stat_part = (float*)si.part;
   }
-  {  // diagnostics: DSX_STAMP_OP=<conv ordinal>[,<block>] -> in-kernel phase stamps of that launch
-    static const char* se = getenv("DSX_STAMP_OP");
-    if (se && mfma_ok) {
-      const int want = atoi(se);
-      const char* comma = strchr(se, ',');
-      if (ex->conv_ordinal == want) {
-        a.stamp = (unsigned long long*)ws_alloc(ex, 128 * 8);
-        a.stamp_block = comma ? atoi(comma + 1) : 0;
-        ex->stamp_buf = a.stamp;
-      }
-    }
-    ex->conv_ordinal++;
-  }
   float* slab = nullptr;
   float* reduce_stats = nullptr;
   if (mfma_ok && a.ksplit > 1) {
@@ -778,13 +820,6 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
     }
   }
   if (ex->sizing) return DSX_OK;
-  const double npix = (double)a.B * a.Ho * a.Wo;
-  const double cin = a.C0 + a.C1;
-  const double flops = 2.0 * npix * a.Cout * cin * ks * ks;
-  const double wbytes = (double)a.Cout * cin * ks * ks * (dtype != 0 ? 2 : 4);
-  const double esz = dtype != 0 ? 2.0 : 4.0;   // activation element size in HBM
-  const double bytes = esz * ((double)a.B * a.Hs * a.Ws * cin + npix * a.Cout * (a.resid ? 1 : 0)) +
-                       (a.out_bf16 ? 2.0 : 4.0) * npix * a.Cout + wbytes;
   if (mfma_ok) {
     const ConvTileInfo ti = conv_tile_info(tile);
     const std::string d = fmt("conv%dx%d%s%s %d->%d @%dx%d tile%dx%d", ks, ks, stride == 2 ? "s2" : "",
@@ -877,17 +912,14 @@ static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* 
 static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tensor* x1, Tensor& y) {
   int rc;
   const int H = x0.H, W = x0.W;
-  float *s1, *h1, *s2, *h2;
-  plan_gn(ex, md.gn1, x0, x1, &s1, &h1);
   Tensor h = new_tensor(ex, md.cout, H, W);
   ConvSpec c1{};
   c1.w = &md.conv1; c1.x0 = x0; if (x1) c1.x1 = *x1;
-  c1.gn_scale = s1; c1.gn_shift = h1; c1.has_gn = true; c1.swish = true;
+  c1.gn = &md.gn1; c1.swish = true;
   if (md.film_off >= 0 && !ex->sizing) { c1.film = ex->film + md.film_off; c1.film_bs = ex->m->F; }
   c1.bias_in_film = md.film_off >= 0 && md.conv1.pb >= 0;
   c1.out = h; c1.want_stats = true;
   if ((rc = plan_conv(ex, c1))) return rc;
-  plan_gn(ex, md.gn2, h, nullptr, &s2, &h2);
   Tensor r;
   if (md.has_res) {
     r = new_tensor(ex, md.cout, H, W);
@@ -899,21 +931,19 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   }
   Tensor o = new_tensor(ex, md.cout, H, W);
   ConvSpec c2{};
-  c2.w = &md.conv2; c2.x0 = h; c2.gn_scale = s2; c2.gn_shift = h2; c2.has_gn = true; c2.swish = true;
-  c2.resid = r.p; c2.resid_ld = md.cout; c2.out = o; c2.want_stats = true;
+  c2.w = &md.conv2; c2.x0 = h; c2.gn = &md.gn2; c2.swish = true;
+  c2.resid = r.p; c2.resid_ld = md.cout; c2.has_resid = true; c2.out = o; c2.want_stats = true;
   if ((rc = plan_conv(ex, c2))) return rc;
   if (!md.attn) { y = o; return DSX_OK; }
   // SelfAttention (unet.py:113-142)
-  float *sa, *ha;
-  plan_gn(ex, md.gna, o, nullptr, &sa, &ha);
   const int C = md.cout, L = H * W, B = ex->B;
   Tensor qkv = new_tensor(ex, 3 * C, H, W);
   ConvSpec cq{};
-  cq.w = &md.qkv; cq.x0 = o; cq.gn_scale = sa; cq.gn_shift = ha; cq.has_gn = true; cq.out = qkv;
+  cq.w = &md.qkv; cq.x0 = o; cq.gn = &md.gna; cq.out = qkv;
   if ((rc = plan_conv(ex, cq))) return rc;
   Tensor av = new_tensor(ex, C, H, W);
   ex->launches += 1;
-  if (!attn_supported(C, L)) return fail(DSX_ERR_INVALID, "attention with head dimension %d is not supported (4..1024, multiple of 4)", C);
+  if (!attn_supported(C, L)) return fail(DSX_ERR_INVALID, "attention with head dimension %d is not supported (8..1024, multiple of 8)", C);
   if (!ex->sizing) {
     AttnArgs g{};
     g.q = qkv.p; g.k = qkv.at(C); g.v = qkv.at(2 * (size_t)C); g.ld = 3 * C;
@@ -925,7 +955,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   }
   Tensor o2 = new_tensor(ex, C, H, W);
   ConvSpec co{};
-  co.w = &md.out; co.x0 = av; co.resid = o.p; co.resid_ld = C; co.out = o2; co.want_stats = true;
+  co.w = &md.out; co.x0 = av; co.resid = o.p; co.resid_ld = C; co.has_resid = true; co.out = o2; co.want_stats = true;
   if ((rc = plan_conv(ex, co))) return rc;
   y = o2;
   return DSX_OK;
@@ -987,11 +1017,9 @@ static int build_plan(dsx_exec* ex) {
       x = y;
       if (md.section == 0) feats.push_back(x);
     } else {
-      float *s, *h;
-      plan_gn(ex, md.gn1, x, nullptr, &s, &h);
       Tensor o = new_tensor(ex, md.cout, x.H, x.W, /*f32=*/true);   // the network's output feeds the fp32 sampler update
       ConvSpec c{};
-      c.w = &md.conv; c.x0 = x; c.gn_scale = s; c.gn_shift = h; c.has_gn = true; c.swish = true; c.out = o;
+      c.w = &md.conv; c.x0 = x; c.gn = &md.gn1; c.swish = true; c.out = o;
       if ((rc = plan_conv(ex, c))) return rc;
       x = o;
     }
