@@ -31,13 +31,13 @@
 #include <utility>
 
 #ifndef DSX_WS_DEPTH_EXPR
-#define DSX_WS_DEPTH_EXPR (bm == 64 ? 5 : (ks == 1 ? 3 : 4))   // measured: one more group in flight than the HBM latency strictly needs
+#define DSX_WS_DEPTH_EXPR (bm == 64 ? 5 : (bm == 256 ? 3 : (ks == 1 ? 3 : 4)))   // measured: one more group in flight than the HBM latency strictly needs
 #endif
 // residual prefetch one tile ahead: only with one N block per wave.  With two, the register demand passes 256 and
 // hipcc (ROCm 7.2) fails in its spill path ("Illegal instruction detected: Operand has incorrect register class
 // V_CMP_NE_U32_e32 0, $src_private_base"); the same happens for a 64 x 256 tile (MB 2, WM 1, WN 4, NB 2).
 #ifndef DSX_PRE_RESID_EXPR
-#define DSX_PRE_RESID_EXPR (NB == 1)
+#define DSX_PRE_RESID_EXPR (NB == 1 && MB <= 2)
 #endif
 #ifndef DSX_PF
 #define DSX_PF 2
@@ -1592,6 +1592,175 @@ hipError_t launch_conv_img(int dtype, int ks, const ConvArgs& a, hipStream_t st)
        : dtype == 2 ? launch_img_dt<_Float16>(ks, &a, lds, st) : launch_img_dt<float>(ks, &a, lds, st);
 }
 
+
+// ===========================================================================================
+// First conv of the UNet (downs.0: 3 x 3, 1..7 input channels -> 16..64 output channels, no GroupNorm in front).
+//
+// With so few input channels the per-tap channel chunk of the implicit-GEMM kernels is almost all padding
+// (6 of 32 channels x 9 taps) and their staging falls back to per-element loads.  Here the whole receptive
+// field is ONE K dimension, k = tap * Cin + c (K = 9 Cin <= 63, padded to 64): a 16 x 16 pixel tile's halo
+// patch sits in LDS as [y][x][Cin], a lane gathers its 8 consecutive k's of a step with 2-byte LDS reads through
+// a per-lane table of k -> patch offsets that is the same for every pixel, weights (packed [N block][k step] in
+// fragment order) live in registers.  The layer is HBM-bound: it writes B * H * W * Cout activations and reads
+// almost nothing.  Epilogue + fused GroupNorm statistics as in the other kernels (one partial row per (tile, wave)).
+// ===========================================================================================
+template <typename DT>
+__global__ __launch_bounds__(256) void k_conv_first(const ConvArgs a) {
+  constexpr bool F32 = sizeof(DT) == 4;
+  constexpr int ES = (int)sizeof(DT);
+  constexpr int KSTEP = F32 ? 2 : 16;            // k per MFMA
+  constexpr int NS16 = 4;                        // 16-bit: K padded to 64
+  __shared__ __attribute__((aligned(16))) unsigned char sm[18 * 18 * 7 * 4 + 64 * 4];
+  DT* patch = (DT*)sm;
+  int* kofft = (int*)(sm + 18 * 18 * 7 * 4);     // fp32 path: k -> element offset inside the patch
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int Cin = a.C0 + a.C1, K = 9 * Cin;
+  const int tiles_x = a.Wo >> 4, tiles_y = a.Ho >> 4;
+  const int t = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int oy0 = ty * 16, ox0 = tx * 16;
+  const int NBLK = (a.Cout + 31) >> 5;           // 1 or 2
+
+  // ---- halo patch -> LDS [18][18][Cin] (zero outside the image)
+  for (int e = tid; e < 18 * 18 * Cin; e += 256) {
+    const int c = e % Cin, pp = e / Cin, px = pp % 18, py = pp / 18;
+    const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+    DT v = (DT)0.f;
+    if (iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) {
+      const size_t pix = ((size_t)b * a.Hs + iy) * a.Ws + ix;
+      v = c < a.C0 ? ((const DT*)a.src0)[pix * a.C0 + c] : ((const DT*)a.src1)[pix * a.C1 + (c - a.C0)];
+    }
+    patch[e] = v;
+  }
+  if (F32 && tid < 64) {
+    const int k = tid < K ? tid : 0;             // padded k: weight 0, any finite element
+    const int tap = k / Cin, c = k - tap * Cin;
+    kofft[tid] = ((tap / 3) * 18 + (tap % 3)) * Cin + c;
+  }
+  // 16-bit path: this lane's k's (the same for every pixel): k = 16 s + 8 lh + j
+  int koff[F32 ? 1 : NS16 * 8];
+  if constexpr (!F32) {
+#pragma unroll
+    for (int s = 0; s < NS16; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int k = 16 * s + 8 * lh + j;
+        if (k >= K) k = 0;
+        const int tap = k / Cin, c = k - tap * Cin;
+        koff[s * 8 + j] = (((tap / 3) * 18 + (tap % 3)) * Cin + c) * 2;
+      }
+  }
+  // weights: [N block][k step][lane][16 B] (16-bit) or [N block][k step][lane] floats (fp32), rows permuted as in pack_conv
+  uint4 wf[F32 ? 1 : 2 * NS16];
+  if constexpr (!F32) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int s = 0; s < NS16; ++s)
+        wf[nb * NS16 + s] = nb < NBLK ? ((const uint4*)a.wpack)[(nb * NS16 + s) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = (wave * 2 + mb) * 32 + li;     // pixel of the 16 x 16 tile
+    const int base = ((m >> 4) * 18 + (m & 15)) * Cin;
+    if constexpr (F32) {
+      const int nsteps = (K + 1) >> 1;
+      const float* wp = (const float*)a.wpack;
+      for (int s = 0; s < nsteps; ++s) {
+        const float pv = ((const float*)patch)[base + kofft[2 * s + lh]];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          if (nb < NBLK) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(nb * 32 + s) * 64 + lane], pv, acc[mb][nb], 0, 0, 0);
+        }
+      }
+    } else {
+      const unsigned char* pb = (const unsigned char*)patch + base * 2;
+#pragma unroll
+      for (int s = 0; s < NS16; ++s) {
+        unsigned w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned lo = *(const unsigned short*)(pb + koff[s * 8 + 2 * q]);
+          const unsigned hi = *(const unsigned short*)(pb + koff[s * 8 + 2 * q + 1]);
+          w4[q] = lo | (hi << 16);
+        }
+        const f32x4_t px = __builtin_bit_cast(f32x4_t, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          if (nb < NBLK) acc[mb][nb] = mfma_step<DT>(wf[nb * NS16 + s], px, acc[mb][nb]);
+      }
+    }
+  }
+  (void)KSTEP; (void)ES;
+
+  // ---- epilogue: + bias, store (16 consecutive channels per lane), GroupNorm partial sums per (tile, wave)
+  const int okind = a.out_bf16;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int nbase = nb * 32 + 16 * lh;
+    if (nb >= NBLK) continue;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    const bool live = nbase < a.Cout;            // Cout is a multiple of 16
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int m = (wave * 2 + mb) * 32 + li;
+      const size_t opix = ((size_t)b * a.Ho + (oy0 + (m >> 4))) * a.Wo + (ox0 + (m & 15));
+      float x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = acc[mb][nb][r];
+      if (live) {
+        if (a.bias) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float4 tt = *(const float4*)(a.bias + nbase + 4 * j); x[4 * j] += tt.x; x[4 * j + 1] += tt.y; x[4 * j + 2] += tt.z; x[4 * j + 3] += tt.w; }
+        }
+        store16<true>(a.out, opix * a.out_ld + nbase, x, okind, 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[r] += x[r]; s2[r] += x[r] * x[r]; }
+      }
+    }
+    if (a.stat_part != nullptr) {
+      float w1 = row16_fold(s1, lane), w2 = row16_fold(s2, lane);
+      w1 += __shfl_xor(w1, 16, 64);
+      w2 += __shfl_xor(w2, 16, 64);
+      const int nch = tiles_x * tiles_y * 4, chunk = t * 4 + wave;
+      const int n = nbase + row16_fold_reg(li);
+      if (li < 16 && n < a.Cout) {
+        float* pp = a.stat_part + (((size_t)b * nch + chunk) * a.Cout + n) * 2;
+        pp[0] = w1; pp[1] = w2;
+      }
+    }
+  }
+}
+
+bool conv_first_applicable(int ks, int stride, const ConvArgs& a, bool gn) {
+  static const int on = getenv("DSX_FIRST") ? atoi(getenv("DSX_FIRST")) : 1;
+  const int C = a.C0 + a.C1;
+  return on && ks == 3 && stride == 1 && !a.up && !gn && !a.swish && C >= 1 && C <= 7 && a.Cout >= 16 && a.Cout <= 64 &&
+         (a.Cout & 15) == 0 && (a.Ho & 15) == 0 && (a.Wo & 15) == 0 && a.Ho == a.Hs && a.Wo == a.Ws && a.out_ld == a.Cout;
+}
+hipError_t launch_conv_first(int dtype, const ConvArgs& a, hipStream_t st) {
+  const unsigned grid = (unsigned)(a.B * (a.Ho >> 4) * (a.Wo >> 4));
+  if (dtype == 1) hipLaunchKernelGGL(k_conv_first<__bf16>, dim3(grid), dim3(256), 0, st, a);
+  else if (dtype == 2) hipLaunchKernelGGL(k_conv_first<_Float16>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_conv_first<float>, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ dispatch
 struct TileCfg { int MB, WM, WN; };
 static constexpr TileCfg kTiles[TILE_COUNT] = {
@@ -1601,6 +1770,8 @@ static constexpr TileCfg kTiles[TILE_COUNT] = {
     {4, 2, 2},  // 256 x 64
     {2, 2, 2},  // 128 x 64
     {1, 2, 2},  // 64 x 64
+    {1, 4, 1},  // 128 x 32: layers with <= 32 output channels (the final conv, 16-channel Hagen levels): all four
+                // waves along M, no wave multiplies padding columns
 };
 
 ConvTileInfo conv_tile_info(int tile) {
@@ -1611,7 +1782,7 @@ ConvTileInfo conv_tile_info(int tile) {
 int conv_tile_wm(int tile) { return kTiles[tile].WM; }
 bool conv_tile_fuses_stats(int tile) { return kTiles[tile].MB <= 2; }
 bool conv_ws_fuses_stats(int tile) {
-  return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;
+  return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64 || tile == TILE_256x64;
 }
 
 static constexpr int conv_cpg(int ks) { return ks == 1 ? 2 : 1; }
@@ -1689,6 +1860,7 @@ static hipError_t launch_dt(int tile, int ks, int stride, const ConvArgs* a, siz
     DSX_TILE_CASE(TILE_64x128)
     DSX_TILE_CASE(TILE_256x64)
     DSX_TILE_CASE(TILE_128x64)
+    DSX_TILE_CASE(TILE_128x32)
     default: return ks == 3 ? launch_one<DT, TILE_64x64, 3, 1>(a, lds, st) : launch_one<DT, TILE_64x64, 1, 1>(a, lds, st);
   }
 #undef DSX_TILE_CASE
@@ -1709,10 +1881,11 @@ static constexpr WsTileCfg ws_tile(int tile) {
   return tile == TILE_128x128 ? WsTileCfg{2, 2, 2, 2}
        : tile == TILE_64x128  ? WsTileCfg{2, 1, 4, 1}
        : tile == TILE_128x64  ? WsTileCfg{2, 2, 2, 1}
+       : tile == TILE_256x64  ? WsTileCfg{4, 2, 2, 1}    // 16 x 16 pixels: half the tiles (and epilogues) of 128 x 64
                               : WsTileCfg{1, 2, 2, 1};   // TILE_64x64
 }
 static constexpr bool ws_tile_ok(int tile) {
-  return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64;
+  return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64 || tile == TILE_256x64;
 }
 int conv_ws_tile_wm(int tile) { return ws_tile(tile).WM; }
 static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activations in flight beyond the current one
@@ -1724,7 +1897,7 @@ static constexpr int kWsLoaderWaves = 4;
 // 8x8 -> 10x10, 16x4 -> 18x6); other shapes fall back to k_conv_mfma
 static constexpr int ws_max_px(int tile, int ks) {
   const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
-  return ks == 1 ? bm : (bm == 128 ? 180 : 108);
+  return ks == 1 ? bm : (bm == 256 ? 324 : (bm == 128 ? 180 : 108));
 }
 static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units per loader thread per group
   const int upg = 4 * conv_cpg(ks);
@@ -1733,6 +1906,7 @@ static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units pe
 }
 size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   if (!ws_tile_ok(tile) || !(ks == 1 || ks == 3)) return 0;
+  if (tile == TILE_256x64 && ks != 3) return 0;
   if (ws_tile(tile).NB == 2 && dtype == 0) return 0;
   if (conv_lds_bytes(dtype, tile, ks, 1, a) == 0) return 0;
   if (patch_pixels(ks, 1, a) > ws_max_px(tile, ks)) return 0;
@@ -1761,7 +1935,7 @@ static hipError_t launch_ws_one(const ConvArgs* ap, size_t lds, hipStream_t st) 
     constexpr WsTileCfg t = ws_tile(TILE);
     constexpr int CPG = conv_cpg(KS);
     // weight ring, in steps: a full group for one N block per wave, half of it (same bytes, same time) for two
-    constexpr int D = KS == 1 ? 4 : (t.NB == 2 ? 6 : 18);
+    constexpr int D = KS == 1 ? 4 : ((t.NB == 2 || t.MB == 4) ? 6 : 18);   // (MB 4: four MFMAs per step, and the registers are needed)
     constexpr int NIT = ws_nit(Kind<DT>::value, TILE, KS);
     constexpr int P = ws_depth(TILE, KS);
     auto kern = k_conv_ws<DT, t.MB, t.WM, t.WN, t.NB, KS, CPG, D, NIT, P, kWsLoaderWaves>;
@@ -1781,6 +1955,7 @@ static hipError_t launch_ws_dt(int tile, int ks, const ConvArgs* a, size_t lds, 
     DSX_WS_CASE(TILE_128x128)
     DSX_WS_CASE(TILE_64x128)
     DSX_WS_CASE(TILE_128x64)
+    DSX_WS_CASE(TILE_256x64)
     DSX_WS_CASE(TILE_64x64)
     default: return hipErrorInvalidValue;
   }

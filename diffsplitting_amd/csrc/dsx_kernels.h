@@ -61,7 +61,7 @@ struct ConvArgs {
 };
 
 // tile configurations compiled for the MFMA conv kernel
-enum ConvTile { TILE_256x128 = 0, TILE_128x128, TILE_64x128, TILE_256x64, TILE_128x64, TILE_64x64, TILE_COUNT };
+enum ConvTile { TILE_256x128 = 0, TILE_128x128, TILE_64x128, TILE_256x64, TILE_128x64, TILE_64x64, TILE_128x32, TILE_COUNT };
 struct ConvTileInfo { int BM, BN; };
 ConvTileInfo conv_tile_info(int tile);
 int conv_tile_wm(int tile);   // waves along M (one statistics row per (tile, wm))
@@ -82,6 +82,10 @@ hipError_t launch_conv_ws(int dtype, int tile, int ks, const ConvArgs& a, hipStr
 // no reduce launch, no k_gn_finalize launch.  `gn` says whether a GroupNorm precedes the conv.
 bool conv_img_applicable(int dtype, int ks, int stride, const ConvArgs& a, bool gn, int gn_groups);
 hipError_t launch_conv_img(int dtype, int ks, const ConvArgs& a, hipStream_t st);
+// first conv of the UNet (1..7 input channels): the 9 taps x Cin receptive field as ONE K dimension on the MFMA;
+// a.wpack = the im2col-ordered pack (pack_first in dsx_runtime.cpp).  One GroupNorm partial row per (16x16 tile, wave).
+bool conv_first_applicable(int ks, int stride, const ConvArgs& a, bool gn);
+hipError_t launch_conv_first(int dtype, const ConvArgs& a, hipStream_t st);
 // one-time function attributes (dynamic LDS limit); call outside any stream capture
 hipError_t conv_init();
 hipError_t ops_init();

@@ -66,6 +66,7 @@ struct ConvW {
   int cin = 0, cout = 0, ks = 1;
   int kchunks = 0, nblocks = 0;
   void* pack = nullptr;     // device, fragment order
+  void* pack_first = nullptr;   // device, im2col order of k_conv_first (few-input-channel 3x3 convs only)
   float* bias = nullptr;    // device
   float* naive = nullptr;   // device [Cout][ks][ks][Cin] (debug / 7x7 only)
 };
@@ -358,6 +359,38 @@ static void pack_conv(const float* w, int cout, int cin, int ks, int dtype, std:
           }
 }
 
+// OIHW fp32 3x3 weights with cin <= 7 -> k_conv_first's operand: K = 9 cin as one dimension, k = tap * cin + c.
+// 16-bit: [nblk][4 k-steps][lane][8 elements], element j of lane (i, h) = W[n(i)][16 s + 8 h + j];
+// fp32: [nblk][32 k-steps][lane] floats, lane (i, h) = W[n(i)][2 s + h].  Rows permuted like pack_conv.
+static void pack_first(const float* w, int cout, int cin, int dtype, std::vector<char>& dst) {
+  const int K = 9 * cin, nblocks = (cout + 31) / 32;
+  auto wk = [&](int n, int k) -> float {
+    if (n >= cout || k >= K) return 0.f;
+    const int tap = k / cin, c = k % cin;
+    return w[((size_t)n * cin + c) * 9 + tap];
+  };
+  auto row = [](int nb, int i) { return nb * 32 + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); };
+  if (dtype == DSX_DTYPE_F32) {
+    dst.assign((size_t)nblocks * 32 * 64 * 4, 0);
+    for (int nb = 0; nb < nblocks; ++nb)
+      for (int s = 0; s < 32; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const float v = wk(row(nb, lane & 31), 2 * s + (lane >> 5));
+          memcpy(dst.data() + (((size_t)nb * 32 + s) * 64 + lane) * 4, &v, 4);
+        }
+  } else {
+    dst.assign((size_t)nblocks * 4 * 64 * 16, 0);
+    for (int nb = 0; nb < nblocks; ++nb)
+      for (int s = 0; s < 4; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const float v = wk(row(nb, lane & 31), 16 * s + 8 * (lane >> 5) + j);
+            const uint16_t hbits = dtype == DSX_DTYPE_BF16 ? f2bf(v) : f2h(v);
+            memcpy(dst.data() + ((((size_t)nb * 4 + s) * 64 + lane) * 8 + j) * 2, &hbits, 2);
+          }
+  }
+}
+
 extern "C" int dsx_model_finalize(dsx_model* m, int dtype) {
   if (!m) return fail(DSX_ERR_INVALID, "null model");
   if (dtype != DSX_DTYPE_F32 && dtype != DSX_DTYPE_BF16 && dtype != DSX_DTYPE_F16) return fail(DSX_ERR_INVALID, "bad dtype");
@@ -401,6 +434,13 @@ extern "C" int dsx_model_finalize(dsx_model* m, int dtype) {
     size_t off = reserve(pk.size());
     memcpy(img.data() + off, pk.data(), pk.size());
     fix.push_back({&c.pack, off});
+    if (c.ks == 3 && c.cin <= 7) {
+      std::vector<char> pf;
+      pack_first(m->params[c.pw].host.data(), c.cout, c.cin, dtype, pf);
+      size_t off2 = reserve(pf.size());
+      memcpy(img.data() + off2, pf.data(), pf.size());
+      fix.push_back({&c.pack_first, off2});
+    }
     if (c.pb >= 0) put_f32(m->params[c.pb].host, &c.bias);
     if (m->want_naive) {
       std::vector<float> nv((size_t)c.cout * c.ks * c.ks * c.cin);
@@ -628,6 +668,7 @@ static bool tile_geometry(int dtype, int tile, int ks, int stride, const ConvArg
 static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out) {
   static const std::vector<int> wide = tile_order("DSX_TILES_WIDE", {TILE_128x128, TILE_64x128, TILE_64x64});
   static const std::vector<int> narrow = tile_order("DSX_TILES_NARROW", {TILE_64x64, TILE_128x64});
+  static const std::vector<int> slim = tile_order("DSX_TILES_SLIM", {TILE_128x32, TILE_64x64, TILE_128x64});   // Cout <= 32
   static const std::vector<int> wide2 = tile_order("DSX_TILES_WIDE_SPLIT", {TILE_64x128, TILE_128x128, TILE_64x64});
   static const std::vector<int> narrow2 = tile_order("DSX_TILES_NARROW_SPLIT", {TILE_64x64, TILE_128x64});
   static const int min_grid = getenv("DSX_MIN_GRID") ? atoi(getenv("DSX_MIN_GRID")) : 512;
@@ -645,7 +686,7 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   static const std::vector<int> ws_wide3 = tile_order("DSX_TILES_WS_WIDE", {TILE_128x128, TILE_64x128});
   static const std::vector<int> ws_wide1 = tile_order("DSX_TILES_WS_WIDE_1X1", {TILE_128x128, TILE_64x128});
   const std::vector<int>& ws_wide = ks == 1 ? ws_wide1 : ws_wide3;
-  static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_128x64, TILE_64x64});
+  static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_256x64, TILE_128x64, TILE_64x64});
   if (ws_on && stride == 1 && a.stage_mode == 0) {
     for (int tile : (is_wide ? ws_wide : ws_narrow)) {
       if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
@@ -653,14 +694,14 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
       if ((long long)c.m_tiles * c.n_tiles >= ws_min) { a = c; tile_out = tile; return true; }
     }
   }
-  for (int tile : (is_wide ? wide : narrow)) {
+  for (int tile : (is_wide ? wide : (a.Cout <= 32 ? slim : narrow))) {
     if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
     if ((long long)c.m_tiles * c.n_tiles >= min_grid) { a = c; tile_out = tile; return true; }
   }
   int best = -1;
   long long best_eff = -1;
   ConvArgs best_a = a;
-  for (int tile : (is_wide ? wide2 : narrow2)) {
+  for (int tile : (is_wide ? wide2 : (a.Cout <= 32 ? slim : narrow2))) {
     if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
     const long long grid = (long long)c.m_tiles * c.n_tiles;
     long long eff = grid;
@@ -754,6 +795,23 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       }
     }
     ex->conv_ordinal++;
+  }
+  // ---- the UNet's first conv (few input channels): im2col-in-K kernel
+  if (!ex->m->want_naive && !s.film && !s.resid && !s.has_resid && conv_first_applicable(ks, stride, a, s.gn != nullptr)) {
+    ex->launches++;
+    a.wpack = s.w->pack_first;
+    if (s.want_stats) {
+      StatInfo& si = ex->stats[s.out.id];
+      si.nchunk = (a.Ho >> 4) * (a.Wo >> 4) * 4;
+      si.part = ws_alloc(ex, (size_t)a.B * si.nchunk * a.Cout * 2 * sizeof(float));
+      si.planned = true;
+      si.f32 = true;
+      a.stat_part = (float*)si.part;
+    }
+    if (ex->sizing) return DSX_OK;
+    add_op(ex, DSX_OP_CONV_MFMA, fmt("conv3x3 %d->%d @%dx%d first", (int)cin, a.Cout, a.Ho, a.Wo), flops, bytes,
+           [=](hipStream_t st) { return launch_conv_first(dtype, a, st); });
+    return DSX_OK;
   }
   // ---- 8 x 8 maps: the image-resident kernel (GroupNorm finalised in its prologue, statistics in its epilogue)
   if (!ex->m->want_naive && conv_img_applicable(dtype, ks, stride, a, s.gn != nullptr, ex->m->cfg.norm_groups)) {

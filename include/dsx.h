@@ -113,7 +113,7 @@ int dsx_exec_num_launches(const dsx_exec* ex);
  * launches in order, what each computes, and an eager hipEvent-timed replay. */
 enum { DSX_OP_CONV_MFMA = 0, DSX_OP_CONV_NAIVE = 1, DSX_OP_GN_STATS = 2, DSX_OP_GN_FINALIZE = 3,
        DSX_OP_ATTN_GEMM = 4 /* the fused attention kernel */, DSX_OP_SOFTMAX = 5 /* unused since ABI 2 */,
-       DSX_OP_SPLITK_REDUCE = 6, DSX_OP_STREAM_CONV = 7 /* few-channel first / last conv */ };
+       DSX_OP_SPLITK_REDUCE = 6 };
 int dsx_exec_num_ops(const dsx_exec* ex);
 int dsx_exec_op_info(const dsx_exec* ex, int index, char* desc_buf, int desc_cap, int* kind,
                      double* flops, double* bytes);
