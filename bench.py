@@ -153,6 +153,36 @@ def roofline(eng, ex, dtype, iters=3):
             "all_kernels_ms_per_step_eager_events": total_ms}
 
 
+def dry_run(args, rank, world):
+    """The distributed skeleton of main() on CPU with gloo: barrier, stubbed step time, MAX over ranks, the final
+    all-gather of the images, rank 0 prints the JSON line (marked "dry": true, not a measurement)."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    B, K = args.batch, args.steps
+    elapsed = 1e-3 * K * (1.0 + 0.1 * rank)                        # stub: rank r is 10 r % slower
+    x = torch.full((B, 3, 8, 8), float(rank))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        out = torch.empty((world * B, 3, 8, 8))
+        dist.all_gather_into_tensor(out, x)
+        x = out
+    assert x.shape[0] == world * B and float(x[-1, 0, 0, 0]) == world - 1
+    ms = elapsed * 1e3 / K
+    if rank == 0:
+        print(json.dumps({"metric": "sampled images/sec (2000-step 128x128 SR3)", "dry": True,
+                          "value": world * B / (ms * 1e-3 * SAMPLE_STEPS), "unit": "images/s", "n_gpus": world,
+                          "steps": K, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "none (dry run)"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,13 +195,24 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--split", type=int, default=int(os.environ.get("DSX_BENCH_SPLIT", "1")),
                     help="run the per-GPU batch as this many independent sub-batches on separate HIP streams")
+    ap.add_argument("--dry", action="store_true",
+                    help="launcher / collective rehearsal on CPU (gloo): no kernels run, the timing is a stub and "
+                         "the JSON line says so; used by the CPU tests of the N > 1 path")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start N fresh ranks ourselves, BEFORE anything touches the GPU
+    from diffsplitting_amd import parallel
+    if parallel.needs_self_launch(args.gpus):
+        raise SystemExit(parallel.self_launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(torchrun --nproc-per-node {args.gpus}, or plain `python bench.py --gpus {args.gpus}`)")
+    if args.dry:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -7,6 +7,9 @@ owns tiles ``r, r+W, r+2W, …`` (keeps every rank's share spread over frames),
 runs its reverse loops, then all ranks exchange predictions once.
 """
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -25,6 +28,47 @@ def init(backend=None):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend)
     return rank(), world_size()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def needs_self_launch(n):
+    """True when ``n`` > 1 ranks were asked for but this process was not started by a launcher."""
+    return int(n) > 1 and "WORLD_SIZE" not in os.environ
+
+
+def self_launch(n, argv, timeout=None):
+    """Start ``n`` fresh children ``python argv...`` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    rendezvous on 127.0.0.1) and wait for them.  Must be called BEFORE this process touches the GPU: the children
+    are new processes (never an exec of a process that has initialised HIP).  Rank 0's stdout is forwarded to ours,
+    every rank's stderr to ours; returns 0 only if every child exited 0."""
+    n = int(n)
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out0, _ = procs[0].communicate(timeout=timeout)
+    rcs = [procs[0].returncode] + [p.wait(timeout=timeout) for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0.decode(errors="replace"))
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"[self_launch] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return 1
+    return 0
 
 
 def rank():

@@ -13,6 +13,7 @@ the engine is inference-only.
 import argparse
 import logging
 import os
+import sys
 import time
 
 import numpy as np
@@ -38,9 +39,16 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None, help="override beta_schedule.val.n_timestep")
     ap.add_argument("--batch-tiles", type=int, default=8)
     ap.add_argument("--dtype", type=str, default=None, choices=["f32", "bf16", "f16"])
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks to run (one process per GPU); default: the number of ids in -gpu.  Without a "
+                         "launcher (torchrun) the ranks are started here")
     args = ap.parse_args(argv)
     if args.phase == "train":
         raise SystemExit("training is out of scope of the MI355X sampling engine; use -p val")
+    n_ranks = args.gpus if args.gpus is not None else len(str(args.gpu_ids).split(","))
+    if argv is None and parallel.needs_self_launch(n_ranks):
+        # fresh child processes, started before anything here touches the GPU (never an exec after HIP init)
+        raise SystemExit(parallel.self_launch(n_ranks, ["-m", "diffsplitting_amd.split"] + sys.argv[1:]))
 
     rank, world = parallel.init()
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(message)s")

@@ -51,3 +51,44 @@ def test_shard_ids_partition():
             ids = sorted(i for r in range(world) for i in parallel.shard_ids(total, r, world))
             assert ids == list(range(total))
             assert sum(parallel.shard_count(total, r, world) for r in range(world)) == total
+
+
+# ----------------------------------------------------------------------------- self-launching entry points
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_self_launches_n_ranks_dry():
+    """`python bench.py --gpus 2` without a launcher starts 2 fresh ranks itself (gloo, kernels stubbed by --dry):
+    rank 0's JSON line reports n_gpus = 2, the MAX over ranks of the stubbed step time and the aggregate rate."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1",
+                        "--dry"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dry"] is True and line["steps"] == 10
+    assert abs(line["ms_per_step"] - 1.1) < 1e-9                      # MAX over ranks of the stub (rank 1: +10 %)
+    assert abs(line["value"] - 2 * 16 / (1.1e-3 * 2000)) < 1e-6       # whole-job aggregate
+
+
+def test_bench_refuses_mismatched_world():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_self_launch_reports_a_failing_rank(tmp_path):
+    import subprocess
+    import sys
+    script = tmp_path / "child.py"
+    script.write_text("import os, sys\nprint('rank', os.environ['RANK'])\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    code = ("import sys; sys.path.insert(0, %r)\nfrom diffsplitting_amd import parallel\n"
+            "sys.exit(parallel.self_launch(2, [%r]))\n" % (ROOT, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "rank 0" in r.stdout and "ranks failed" in r.stderr
