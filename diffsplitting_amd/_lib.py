@@ -27,7 +27,8 @@ class UnetCfg(C.Structure):
 class StepTable(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("predict_eps", C.c_int32), ("clip", C.c_int32),
                 ("tcond", C.POINTER(C.c_float)), ("a", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float)),
-                ("c1", C.POINTER(C.c_float)), ("c2", C.POINTER(C.c_float)), ("sigma", C.POINTER(C.c_float))]
+                ("c1", C.POINTER(C.c_float)), ("c2", C.POINTER(C.c_float)), ("sigma", C.POINTER(C.c_float)),
+                ("per_sample", C.c_int32)]
 
 
 FLAVOUR_SR3, FLAVOUR_DDPM = 0, 1
@@ -70,6 +71,8 @@ SIGNATURES = {
     "dsx_tile_regions": (_i, [_pi64, _pi64, _pi64, _i, _pi32, _i64]),
     "dsx_tiles_gather": (_i, [_vp, _pi64, _pi64, _pi64, _pi64, _i64, _vp, _vp]),
     "dsx_stitch": (_i, [_vp, _i64, _i, _i, _i, _pi32, _vp, _pi64, _vp]),
+    "dsx_stitch_psnr_blocks": (_i, [_i, _i]),
+    "dsx_stitch_psnr": (_i, [_vp, _i64, _i, _i, _i, _pi32, _vp, _pi64, _vp, _vp, _vp]),
 }
 
 if not os.path.exists(LIB_PATH):

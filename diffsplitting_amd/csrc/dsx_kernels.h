@@ -130,8 +130,9 @@ struct TembArgs {
   int B;                  // rows to produce
   int n_time;             // B or 1 (broadcast)
   const float* time;      // direct time values, or nullptr -> table[*step_ctr]
-  const float* table;     // per-step tcond table (device)
+  const float* table;     // per-step tcond table (device); per_sample: [step][B]
   const int* step_ctr;
+  int per_sample;
   int inner;              // C0
   const float* freq;      // [inner/2]
   const float* w1; const float* b1;   // [4*inner][inner], [4*inner]
@@ -192,6 +193,7 @@ struct UpdateArgs {
   int n_steps;            // column stride of `tab` (its capacity)
   const int* step_ctr;
   int predict_eps, clip;
+  int per_sample;         // the table columns hold [step][B] values instead of one per step
   int B, C, H, W;
 };
 hipError_t launch_update(const UpdateArgs& a, hipStream_t st);
@@ -205,6 +207,11 @@ hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw
 hipError_t launch_stitch(const float* tiles, long long count, int C, int ph, int pw,
                          const int* regions /*dev [count][8]*/, float* canvas, int H, int W,
                          hipStream_t st);
+
+// stitch + per-(tile, workgroup, channel) partial sums for RangeInvariantPsnr: part[count][gx][C][8] doubles
+// {sum p, sum p^2, sum g, sum g^2, sum g p, min g, max g, 0}
+hipError_t launch_stitch_psnr(const float* tiles, long long count, int C, int ph, int pw, const int* regions,
+                              float* canvas, const float* gt, int H, int W, double* part, int gx, hipStream_t st);
 
 // relu(u) * sigmoid-mask reduction of the TimePredictor head
 hipError_t launch_masked_mean(const float* u, const float* mask, int B, long long n, float* out,

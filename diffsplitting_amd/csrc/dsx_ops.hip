@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_temb(const TembArgs a) {
   const int b = blockIdx.x;
   float tv;
   if (a.time) tv = a.time[a.n_time == 1 ? 0 : b];
-  else tv = a.table[*a.step_ctr];
+  else tv = a.per_sample ? a.table[(size_t)*a.step_ctr * a.B + b] : a.table[*a.step_ctr];
   const int half = inner / 2;
   for (int i = threadIdx.x; i < inner; i += 256) {
     const int k = i < half ? i : i - half;
@@ -405,8 +405,11 @@ hipError_t launch_randn(float* out, long long n, unsigned long long seed, unsign
 __global__ void k_update(const UpdateArgs a) {
   const int step = *a.step_ctr;
   const int T = a.n_steps;
-  const float ca = a.tab[1 * T + step], cb = a.tab[2 * T + step];
-  const float c1 = a.tab[3 * T + step], c2 = a.tab[4 * T + step], sg = a.tab[5 * T + step];
+  float ca = 0.f, cb = 0.f, c1 = 0.f, c2 = 0.f, sg = 0.f;
+  if (!a.per_sample) {
+    ca = a.tab[1 * T + step]; cb = a.tab[2 * T + step];
+    c1 = a.tab[3 * T + step]; c2 = a.tab[4 * T + step]; sg = a.tab[5 * T + step];
+  }
   const long long HW = (long long)a.H * a.W;
   const long long n = (long long)a.B * HW * a.C;
   const long long n4 = (n + 3) / 4;
@@ -415,7 +418,7 @@ __global__ void k_update(const UpdateArgs a) {
   for (long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i4 < n4;
        i4 += (long long)gridDim.x * blockDim.x) {
     float z[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!a.use_noise && sg != 0.f) normal4(seed, (unsigned long long)step + 1, (unsigned long long)i4, z);
+    if (!a.use_noise && (a.per_sample || sg != 0.f)) normal4(seed, (unsigned long long)step + 1, (unsigned long long)i4, z);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long i = i4 * 4 + j;  // NHWC linear index
@@ -426,6 +429,11 @@ __global__ void k_update(const UpdateArgs a) {
         const long long p = i / a.C;
         const long long b = p / HW, hw = p % HW;
         zz = noise[(size_t)step * n + (b * a.C + c) * HW + hw];
+      }
+      if (a.per_sample) {   // per-sample schedule: the row of this element's image
+        const size_t k = (size_t)step * a.B + (size_t)(i / (HW * a.C));
+        ca = a.tab[1 * (size_t)T + k]; cb = a.tab[2 * (size_t)T + k];
+        c1 = a.tab[3 * (size_t)T + k]; c2 = a.tab[4 * (size_t)T + k]; sg = a.tab[5 * (size_t)T + k];
       }
       const float x = a.x[i];
       float o = a.net[i];
@@ -495,6 +503,67 @@ hipError_t launch_stitch(const float* tiles, long long count, int C, int ph, int
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(k_stitch, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, st, tiles, C, ph, pw,
                      regions, canvas, H, W);
+  return hipGetLastError();
+}
+
+// Stitch + the sums RangeInvariantPsnr needs (core/psnr.py:70-82), in the same pass: while a tile's valid region
+// is pasted, every (tile, workgroup) also reduces, per channel, sum(p), sum(p^2), sum(g), sum(g^2), sum(g p),
+// min(g), max(g) of prediction p against the ground truth g at the same canvas pixels (every canvas pixel is pasted
+// exactly once).  Fixed reduction order (thread -> wave shuffles -> 4 waves): bitwise reproducible.
+// part[t][blockIdx.x][c][8] doubles; the per-frame combination (a few hundred values) is the caller's.
+constexpr int kPsnrMaxC = 4;
+__global__ __launch_bounds__(256) void k_stitch_psnr(const float* __restrict__ tiles, int C, int ph, int pw,
+                                                      const int* __restrict__ regions, float* __restrict__ canvas,
+                                                      const float* __restrict__ gt, int H, int W, double* __restrict__ part) {
+  __shared__ double red[4][kPsnrMaxC][7];
+  const long long t = blockIdx.y;
+  const int* r = regions + t * 8;
+  const int n = r[0], y0 = r[1], x0 = r[2], h = r[3], w = r[4], ry = r[5], rx = r[6];
+  const float* tile = tiles + (size_t)t * C * ph * pw;
+  double sp[kPsnrMaxC], spp[kPsnrMaxC], sg[kPsnrMaxC], sgg[kPsnrMaxC], sgp[kPsnrMaxC], mn[kPsnrMaxC], mx[kPsnrMaxC];
+#pragma unroll
+  for (int c = 0; c < kPsnrMaxC; ++c) { sp[c] = spp[c] = sg[c] = sgg[c] = sgp[c] = 0; mn[c] = INFINITY; mx[c] = -INFINITY; }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < h * w; i += gridDim.x * blockDim.x) {
+    const int x = i % w, y = i / w;
+    const size_t cpix = (((size_t)n * H + (y0 + y)) * W + (x0 + x)) * C;
+#pragma unroll
+    for (int c = 0; c < kPsnrMaxC; ++c) {
+      if (c < C) {
+        const float p = tile[((size_t)c * ph + (ry + y)) * pw + (rx + x)];
+        const float g = gt[cpix + c];
+        canvas[cpix + c] = p;
+        sp[c] += p; spp[c] += (double)p * p; sg[c] += g; sgg[c] += (double)g * g; sgp[c] += (double)g * p;
+        mn[c] = fmin(mn[c], (double)g); mx[c] = fmax(mx[c], (double)g);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < kPsnrMaxC; ++c) {
+    sp[c] = wave_sum(sp[c]); spp[c] = wave_sum(spp[c]); sg[c] = wave_sum(sg[c]); sgg[c] = wave_sum(sgg[c]);
+    sgp[c] = wave_sum(sgp[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn[c] = fmin(mn[c], __shfl_xor(mn[c], o, 64)); mx[c] = fmax(mx[c], __shfl_xor(mx[c], o, 64)); }
+    if (lane == 0) {
+      red[wave][c][0] = sp[c]; red[wave][c][1] = spp[c]; red[wave][c][2] = sg[c]; red[wave][c][3] = sgg[c];
+      red[wave][c][4] = sgp[c]; red[wave][c][5] = mn[c]; red[wave][c][6] = mx[c];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < C * 8) {
+    const int c = threadIdx.x >> 3, k = threadIdx.x & 7;
+    double v = 0;
+    if (k < 5) v = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+    else if (k == 5) v = fmin(fmin(red[0][c][5], red[1][c][5]), fmin(red[2][c][5], red[3][c][5]));
+    else if (k == 6) v = fmax(fmax(red[0][c][6], red[1][c][6]), fmax(red[2][c][6], red[3][c][6]));
+    part[(((size_t)t * gridDim.x + blockIdx.x) * C + c) * 8 + k] = v;
+  }
+}
+hipError_t launch_stitch_psnr(const float* tiles, long long count, int C, int ph, int pw, const int* regions,
+                              float* canvas, const float* gt, int H, int W, double* part, int gx, hipStream_t st) {
+  if (C < 1 || C > kPsnrMaxC || gx < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_stitch_psnr, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, st, tiles, C, ph, pw, regions,
+                     canvas, gt, H, W, part);
   return hipGetLastError();
 }
 

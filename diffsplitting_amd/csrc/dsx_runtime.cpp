@@ -1260,13 +1260,13 @@ extern "C" int dsx_exec_profile(dsx_exec* ex, int iters, float* ms_per_op, void*
 }
 
 // time embedding + UNet body on `st`; inputs already in ex->in_cond / ex->in_x
-static int run_unet(dsx_exec* ex, bool from_table, int n_time, hipStream_t st) {
+static int run_unet(dsx_exec* ex, bool from_table, int n_time, hipStream_t st, int per_sample = 0) {
   dsx_model* m = ex->m;
   if (m->cfg.with_time_emb) {
     TembArgs t{};
     t.flavour = m->cfg.flavour; t.B = ex->B; t.n_time = n_time;
     t.time = from_table ? nullptr : ex->time_buf;
-    t.table = ex->table; t.step_ctr = ex->step_ctr;
+    t.table = ex->table; t.step_ctr = ex->step_ctr; t.per_sample = per_sample;
     t.inner = m->cfg.inner_channel; t.freq = m->d_freq;
     t.w1 = m->d_w1; t.b1 = m->d_b1; t.w2 = m->d_w2; t.b2 = m->d_b2;
     t.wf = m->d_wf; t.bf = m->d_bf; t.F = m->F; t.film = ex->film;
@@ -1314,7 +1314,7 @@ static int load_inputs(dsx_exec* ex, const float* cond_nchw, const float* x_nchw
 
 // ------------------------------------------------------------------ sampler
 static int ensure_table(dsx_exec* ex, const dsx_step_table* tab) {
-  const int T = tab->n_steps;
+  const int T = tab->n_steps * (tab->per_sample > 0 ? tab->per_sample : 1);   // values per column
   if (T > ex->table_cap) {
     // the table's column stride (= capacity) is baked into captured graphs: drop them
     if (ex->graph_exec) {
@@ -1337,13 +1337,13 @@ static int ensure_table(dsx_exec* ex, const dsx_step_table* tab) {
 }
 
 static int enqueue_step(dsx_exec* ex, const dsx_step_table* tab, bool use_noise, hipStream_t st) {
-  int rc = run_unet(ex, true, 1, st);
+  int rc = run_unet(ex, true, tab->per_sample > 0 ? ex->B : 1, st, tab->per_sample > 0 ? 1 : 0);
   if (rc) return rc;
   UpdateArgs u{};
   u.x = ex->x_state; u.x_act = ex->in_x.st ? ex->in_x.p : nullptr; u.x_act_kind = ex->in_x.st;
   u.net = (const float*)ex->out.p; u.use_noise = use_noise ? 1 : 0; u.loop_params = ex->loop_params;
   u.tab = ex->table; u.n_steps = ex->table_cap; u.step_ctr = ex->step_ctr;
-  u.predict_eps = tab->predict_eps; u.clip = tab->clip;
+  u.predict_eps = tab->predict_eps; u.clip = tab->clip; u.per_sample = tab->per_sample > 0 ? 1 : 0;
   u.B = ex->B; u.C = ex->x_c; u.H = ex->H; u.W = ex->W;
   HIP_TRY(launch_update(u, st));
   HIP_TRY(launch_advance(ex->step_ctr, st));
@@ -1359,6 +1359,8 @@ extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const fl
   if (ex->out.C != ex->x_c)
     return fail(DSX_ERR_INVALID, "UNet out_channel (%d) must equal the state channels (%d)", ex->out.C, ex->x_c);
   if (n_snap > 0 && (!snap_steps || !snaps)) return fail(DSX_ERR_INVALID, "snapshot arrays missing");
+  if (tab->per_sample != 0 && tab->per_sample != ex->B)
+    return fail(DSX_ERR_INVALID, "per_sample step table for %d samples, executor batch %d", tab->per_sample, ex->B);
   hipStream_t st = (hipStream_t)stream;
   const int T = tab->n_steps;
   int rc = ensure_table(ex, tab);
@@ -1377,7 +1379,7 @@ extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const fl
   bool graph_ok = false;
   if (use_graph) {
     // the captured step bakes in the mode flags only (not the step count, the seed or the noise address)
-    std::vector<float> sig = {(float)tab->predict_eps, (float)tab->clip, noise ? 1.f : 0.f};
+    std::vector<float> sig = {(float)tab->predict_eps, (float)tab->clip, noise ? 1.f : 0.f, tab->per_sample > 0 ? 1.f : 0.f};
     if (!ex->graph_exec || sig != ex->graph_sig) {
       if (ex->graph_exec) {
         // a replaced executable graph may still have launches queued: wait for them before destroying it
@@ -1606,5 +1608,33 @@ extern "C" int dsx_stitch(const float* tiles, int64_t count, int C, int ph, int 
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(launch_stitch(tiles, count, C, ph, pw, d_reg, canvas, (int)data_shape[1], (int)data_shape[2], st));
   HIP_TRY(hipFree(d_reg));  // synchronises: the paste has finished
+  return DSX_OK;
+}
+
+// stitch + RangeInvariantPsnr partial sums in one pass over the tiles (no second pass over the canvas)
+extern "C" int dsx_stitch_psnr_blocks(int ph, int pw) {
+  int gx = (ph * pw + 255) / 256;
+  return gx > 16 ? 16 : (gx < 1 ? 1 : gx);
+}
+extern "C" int dsx_stitch_psnr(const float* tiles, int64_t count, int C, int ph, int pw, const int32_t* regions,
+                               float* canvas, const int64_t data_shape[3], const float* gt_canvas, double* partials_dev,
+                               void* stream) {
+  if (!tiles || !regions || !canvas || !data_shape || !gt_canvas || !partials_dev || count < 0 || C < 1 || C > 4)
+    return fail(DSX_ERR_INVALID, "bad argument (1 <= C <= 4)");
+  if (count == 0) return DSX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i = 0; i < count; ++i) {
+    const int32_t* r = regions + i * 8;
+    if (r[0] < 0 || r[0] >= data_shape[0] || r[1] < 0 || r[1] + r[3] > data_shape[1] || r[2] < 0 ||
+        r[2] + r[4] > data_shape[2] || r[5] < 0 || r[5] + r[3] > ph || r[6] < 0 || r[6] + r[4] > pw)
+      return fail(DSX_ERR_INVALID, "region %lld out of bounds", (long long)i);
+  }
+  int* d_reg = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_reg, (size_t)count * 32));
+  HIP_TRY(hipMemcpyAsync(d_reg, regions, (size_t)count * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(launch_stitch_psnr(tiles, count, C, ph, pw, d_reg, canvas, gt_canvas, (int)data_shape[1], (int)data_shape[2],
+                             partials_dev, dsx_stitch_psnr_blocks(ph, pw), st));
+  HIP_TRY(hipFree(d_reg));
   return DSX_OK;
 }

@@ -82,3 +82,45 @@ class TilePlan:
                                  C.c_void_p(canvas.data_ptr()), _i64x3(self.data_shape),
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return canvas
+
+    def stitch_with_psnr(self, tiles, gt):
+        """Stitch ALL tiles (count == total, id order) and compute RangeInvariantPsnr (core/psnr.py:70-82) of every
+        (frame, channel) against ``gt`` (N,H,W,C fp32 CUDA) from sums accumulated while pasting: no second pass
+        over the canvas.  Returns (canvas (N,H,W,C), psnr (N,C) float64 on the device)."""
+        _lib.require_gpu()
+        if tiles.shape[0] != self.total:
+            raise DsxError("stitch_with_psnr needs every tile of the plan")
+        tiles = tiles.contiguous()
+        Cn = tiles.shape[1]
+        gt = gt.to(torch.float32).contiguous()
+        if tuple(gt.shape) != self.data_shape + (Cn,) or not gt.is_cuda:
+            raise DsxError(f"gt must be a CUDA tensor of shape {self.data_shape + (Cn,)}")
+        canvas = torch.zeros(self.data_shape + (Cn,), dtype=torch.float32, device=tiles.device)
+        gx = int(lib.dsx_stitch_psnr_blocks(self.patch_shape[1], self.patch_shape[2]))
+        part = torch.zeros((self.total, gx, Cn, 8), dtype=torch.float64, device=tiles.device)
+        check(lib.dsx_stitch_psnr(C.c_void_p(tiles.data_ptr()), self.total, Cn, self.patch_shape[1], self.patch_shape[2],
+                                  self.regions.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(canvas.data_ptr()),
+                                  _i64x3(self.data_shape), C.c_void_p(gt.data_ptr()), C.c_void_p(part.data_ptr()),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        N = self.data_shape[0]
+        per = self.total // N                                       # tile ids are frame-major (tiling_manager.py:145-154)
+        p = part.view(N, per * gx, Cn, 8)
+        s = p[..., :5].sum(dim=1)                                    # fixed order: reproducible
+        gmin, gmax = p[..., 5].amin(dim=1), p[..., 6].amax(dim=1)
+        return canvas, range_invariant_psnr_from_sums(s[..., 0], s[..., 1], s[..., 2], s[..., 3], s[..., 4], gmin, gmax,
+                                                      float(self.data_shape[1] * self.data_shape[2]))
+
+
+def range_invariant_psnr_from_sums(sp, spp, sg, sgg, sgp, gmin, gmax, n):
+    """core/psnr.py:70-82 in closed form.  With g_ = (g - mean g) / std g (unbiased std, as torch.std) and
+    p0 = p - mean p:  alpha = <g_, p0> / <p0, p0>,  mse = (<g_, g_> - <g_, p0>^2 / <p0, p0>) / n,
+    PSNR = 20 log10( ((max g - min g) / std g) / sqrt(mse) )."""
+    mean_g, mean_p = sg / n, sp / n
+    var_g = (sgg - n * mean_g * mean_g) / (n - 1.0)
+    std_g = torch.sqrt(var_g)
+    gg = (sgg - n * mean_g * mean_g) / var_g                        # = n - 1
+    gp = (sgp - n * mean_g * mean_p) / std_g
+    pp = spp - n * mean_p * mean_p
+    mse = (gg - gp * gp / pp) / n
+    ra = (gmax - gmin) / std_g
+    return 20.0 * torch.log10(ra / torch.sqrt(mse))

@@ -229,16 +229,20 @@ class UNetEngine:
 class StepTableHost:
     """Host-side per-step scalars handed to ``dsx_sample_loop`` (include/dsx.h)."""
 
-    def __init__(self, tcond, c1, c2, sigma, a=None, b=None, predict_eps=False, clip=False):
+    def __init__(self, tcond, c1, c2, sigma, a=None, b=None, predict_eps=False, clip=False, per_sample=0):
+        """Columns of shape (n_steps,), or (n_steps, B) with ``per_sample=B`` (one schedule per batch element)."""
         f = lambda v: None if v is None else np.ascontiguousarray(np.asarray(v, dtype=np.float32))
         self.tcond, self.a, self.b, self.c1, self.c2, self.sigma = f(tcond), f(a), f(b), f(c1), f(c2), f(sigma)
         self.n_steps = int(self.tcond.shape[0])
+        self.per_sample = int(per_sample)
+        if self.per_sample and tuple(self.tcond.shape) != (self.n_steps, self.per_sample):
+            raise DsxError("per-sample step tables hold (n_steps, B) values per column")
         self.predict_eps, self.clip = bool(predict_eps), bool(clip)
 
     def c_struct(self):
         p = lambda v: v.ctypes.data_as(C.POINTER(C.c_float)) if v is not None else None
         return _lib.StepTable(self.n_steps, int(self.predict_eps), int(self.clip), p(self.tcond), p(self.a),
-                              p(self.b), p(self.c1), p(self.c2), p(self.sigma))
+                              p(self.b), p(self.c1), p(self.c2), p(self.sigma), self.per_sample)
 
 
 # ---------------------------------------------------------------------------
@@ -335,6 +339,16 @@ def indi_step_table(num_timesteps, t_float_start, e=0.01):
         sg.append((e * (t_cur - delta)).item())
         cur_t -= delta
     return StepTableHost(ts, c1=c1, c2=c2, sigma=sg, predict_eps=False, clip=False)
+
+
+def indi_step_table_per_sample(num_timesteps, t_starts, e=0.01):
+    """One InDI schedule per batch element (``t_starts``: B floats): the columns of ``indi_step_table`` for every
+    sample, stacked to (n_steps, B).  This is what the reference's refinement driver gets by looping over the batch
+    one sample at a time (core/psnr_based_t_refinement.py:22-36)."""
+    tabs = [indi_step_table(num_timesteps, float(t), e) for t in t_starts]
+    st = lambda k: np.stack([getattr(t, k) for t in tabs], axis=1)
+    return StepTableHost(st("tcond"), c1=st("c1"), c2=st("c2"), sigma=st("sigma"), predict_eps=False, clip=False,
+                         per_sample=len(tabs))
 
 
 def indi_snapshot_steps(num_timesteps):

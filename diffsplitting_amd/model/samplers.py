@@ -155,6 +155,53 @@ class InDISampler(_SamplerBase):
         scale = (self.e * torch.Tensor([t_float_start])).to(dev)     # get_t_times_e, indi.py:106-110
         return x_in + self._draw(x_in.shape, dev) * scale            # indi.py:82
 
+    @staticmethod
+    def _per_sample_t(t_float_start, batch):
+        """None for the reference's scalar start time; else the B per-sample start times as python floats."""
+        if torch.is_tensor(t_float_start):
+            t = t_float_start.detach().reshape(-1).to("cpu", torch.float64).tolist()
+        elif isinstance(t_float_start, (list, tuple)) or (hasattr(t_float_start, "shape") and getattr(t_float_start, "ndim", 0) > 0):
+            t = [float(v) for v in t_float_start]
+        else:
+            return None
+        if len(t) == 1:
+            t = t * batch
+        if len(t) != batch:
+            raise DsxError(f"t_float_start has {len(t)} entries for a batch of {batch}")
+        return t
+
+    @torch.no_grad()
+    def _inference_per_sample(self, x_in, t_list, continuous, num_timesteps, stream):
+        """One start time per batch element, one batched loop (per-sample step tables).  Equivalent to calling
+        ``inference`` on every sample alone, as core/psnr_based_t_refinement.py:26-34 does; with a ``noise_source``
+        the draws are taken sample by sample in that order (start draw, then one draw per step)."""
+        dev = x_in.device
+        B = x_in.shape[0]
+        xr = torch.cat([x_in.float()] * self.out_channel, dim=1)
+        noise = None
+        if self.noise_source is not None:
+            starts, steps = [], []
+            for b in range(B):
+                starts.append(self._draw((1,) + tuple(xr.shape[1:]), dev))
+                steps.append(torch.cat([self._draw((1,) + tuple(xr.shape[1:]), dev) for _ in range(num_timesteps)]))
+            d0 = torch.cat(starts)
+            noise = torch.stack(steps, dim=1).contiguous()            # (n, B, C, H, W)
+        else:
+            d0 = self._draw(xr.shape, dev)
+        scale = torch.stack([(self.e * torch.Tensor([t])) for t in t_list]).to(dev).view(B, 1, 1, 1)
+        x_t = xr + d0 * scale
+        table = engine.indi_step_table_per_sample(num_timesteps, t_list, self.e)
+        snaps = engine.indi_snapshot_steps(num_timesteps) if continuous else []
+        first = x_t.clone() if continuous else None
+        x, sn = self.denoise_fn.engine().sample_loop(table, x_t, noise=noise, seed=self._seed(), snapshot_steps=snaps,
+                                                     use_graph=self.use_graph, stream=stream)
+        self.last_full_batch = x
+        if continuous:
+            if stream is not None:
+                stream.synchronize()
+            return torch.cat([first] + [s for s in sn], dim=0)
+        return x[-1:]
+
     def _noise(self, shape, n, dev):
         if self.noise_source is None:
             return None
@@ -168,6 +215,9 @@ class InDISampler(_SamplerBase):
         assert self.conditional is False
         if not x_in.is_cuda:
             raise DsxError("inference runs on the MI355X only; pass a CUDA tensor (no CPU fallback)")
+        t_list = self._per_sample_t(t_float_start, x_in.shape[0])
+        if t_list is not None:
+            return self._inference_per_sample(x_in, t_list, continuous, num_timesteps, stream)
         x_t = self._start(x_in, t_float_start)
         noise = self._noise(x_t.shape, num_timesteps, x_t.device)
         table = engine.indi_step_table(num_timesteps, t_float_start, self.e)   # no drift assert (R3)

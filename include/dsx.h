@@ -165,6 +165,10 @@ typedef struct dsx_step_table {
   const float* c1;
   const float* c2;
   const float* sigma;
+  /* 0: one row of scalars per step, shared by the batch (the reference's loops).  B (= the executor's batch): every
+   * column holds n_steps * B values, [step][sample] — per-sample schedules, e.g. InDI started at a per-tile t
+   * predicted by the TimePredictor (core/psnr_based_t_refinement.py:22-36 loops over the batch one sample at a time) */
+  int32_t per_sample;
 } dsx_step_table;
 
 /* Runs the whole reverse loop on `stream` without host synchronisation:
@@ -223,6 +227,17 @@ int dsx_tiles_gather(const float* frames_dev, const int64_t data_shape[3],
 int dsx_stitch(const float* tiles_dev, int64_t count, int C, int ph, int pw,
                const int32_t* regions_host, float* canvas_dev, const int64_t data_shape[3],
                void* stream);
+
+/* dsx_stitch plus, in the same pass over the tiles, the sums the reported quality metric needs
+ * (RangeInvariantPsnr, core/psnr.py:70-82) of the pasted prediction p against the ground-truth canvas g
+ * (N,H,W,C fp32): partials_dev receives count * dsx_stitch_psnr_blocks(ph,pw) * C * 8 doubles
+ * {sum p, sum p^2, sum g, sum g^2, sum g p, min g, max g, 0} per (tile, workgroup, channel); the caller adds the
+ * rows of a frame (fixed order) and evaluates the closed form.  Replaces the host-side pass over the 335 MB
+ * stitched canvas (notebooks/EvaluateJointIndi.ipynb cell 30). */
+int dsx_stitch_psnr_blocks(int ph, int pw);
+int dsx_stitch_psnr(const float* tiles_dev, int64_t count, int C, int ph, int pw, const int32_t* regions_host,
+                    float* canvas_dev, const int64_t data_shape[3], const float* gt_canvas_dev, double* partials_dev,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -265,3 +265,38 @@ ks = key_shapes(tp)
 load_synth(tp, ks)
 x = cases.make_fullsize_input("c5_tp_x", (2, 1, 512, 512))
 save("full_c5_timepred", keys=jstr(ks), t=tp(x).numpy())
+
+# ---------------------------------------------------------------- TimePredictor-driven refinement (N3)
+# core/psnr_based_t_refinement.py cannot be imported (it imports the external `disentangle` package, :10, and calls
+# InDI.p_sample_loop with the signature of what is now InDI.inference).  Its 30 lines are followed here literally
+# with the reference's own classes: TimePredictor, InDI.inference (batch 1, sample by sample), core.psnr.
+case = cases.UNET_CASES["joint_32"]
+for nsteps in (1, 2):
+    i1 = InDI(UNetDdpm(**case["cfg"]).eval(), 32, channels=1, out_channel=1, conditional=False,
+              val_schedule_opt={"n_timestep": nsteps}).eval()
+    i2 = InDI(UNetDdpm(**case["cfg"]).eval(), 32, channels=1, out_channel=1, conditional=False,
+              val_schedule_opt={"n_timestep": nsteps}).eval()
+    ks1, ks2 = key_shapes(i1), key_shapes(i2)
+    load_synth(i1, ks1, seed=1)
+    load_synth(i2, ks2, seed=2)
+    tp = TimePredictor(**cases.TIME_PRED_CFG).eval()
+    kst = key_shapes(tp)
+    load_synth(tp, kst)
+    inp = cases.make_cond("time_pred")                              # (3, 1, 32, 32)
+    pred_t_2 = tp(inp)                                              # get_time_prediction_from_classifier (:14-17)
+    pred_t_1 = 1 - pred_t_2
+    torch.manual_seed(cases.LOOP_SEED)
+    p1, p2 = [], []
+    for b in range(inp.shape[0]):                                   # get_channel_estimates (:20-39)
+        p1.append(i1.inference(inp[b:b + 1], continuous=False, num_timesteps=nsteps, t_float_start=pred_t_1[b].item()).numpy())
+        p2.append(i2.inference(inp[b:b + 1], continuous=False, num_timesteps=nsteps, t_float_start=pred_t_2[b].item()).numpy())
+    pred1, pred2 = np.concatenate(p1, axis=0), np.concatenate(p2, axis=0)
+    gt = inp.numpy()[:, 0]                                          # estimate_time_using_PSNR (:41-57)
+    t_list = np.arange(0, 1.0, 0.05)
+    psnr_list = [RangeInvariantPsnr(gt, pred1[:, 0] * t + pred2[:, 0] * (1 - t)) for t in t_list]
+    psnr_matrix = torch.stack(psnr_list)
+    per_sample_t = t_list[psnr_matrix.argmax(dim=0)]
+    concensus_t = t_list[psnr_matrix.mean(dim=1).argmax()]
+    save(f"refine_n{nsteps}", keys1=jstr(ks1), keys2=jstr(ks2), keys_tp=jstr(kst), pred_t=pred_t_2.numpy(),
+         pred1=pred1, pred2=pred2, psnr=psnr_matrix.numpy(), per_sample_t=np.asarray(per_sample_t),
+         concensus_t=np.float64(concensus_t))

@@ -39,3 +39,24 @@ def psnr(ref, x):
 
 def maxabs(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_sr3_loop_tiny(sched, shape, cond_seed=3, draw_seed=77):
+    """The fp32 oracle loop of the tiny SR3 UNet (weights of loop_sr3_lin_8) on a seeded conditioning image with
+    recorded draws; cached: the 2000-step schedule takes the host ~1 minute and several tests compare against it."""
+    from oracle import samplers
+    from tests.util import golden_state_dict
+    sd, _ = golden_state_dict("loop_sr3_lin_8")
+    case = cases.UNET_CASES["sr3_tiny"]
+    sch = cases.SCHEDULES[sched]
+    g = torch.Generator().manual_seed(cond_seed)
+    cond = torch.randn(tuple(shape), generator=g)
+    rec = DrawRecorder(draw_seed)
+    osd = {"denoise_fn." + k: v for k, v in sd.items()}
+    _, full = samplers.sr3_p_sample_loop(osd, case["cfg"], samplers.gaussian_schedule(sch), cond, randn=rec,
+                                         return_full=True)
+    return sd, case, sch, cond, rec.draws, full

@@ -216,3 +216,89 @@ def test_two_rank_predict_tiled():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PREDICT_TILED_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_stitch_with_fused_range_invariant_psnr():
+    """N1: the quality metric accumulated while stitching (no second pass over the canvas).  Fixture: psnr.npz holds
+    gt / pred and RangeInvariantPsnr as the reference's core/psnr.py computed them; the prediction is cut into tiles,
+    stitched back by the HIP kernel, and the fused metric must equal the reference's value."""
+    from diffsplitting_amd.core.psnr import RangeInvariantPsnr
+    from diffsplitting_amd.data.tiling import TilePlan
+    g = load_golden("psnr")
+    gt = torch.from_numpy(g["gt"]).cuda()
+    pred = torch.from_numpy(g["pred"]).cuda()
+    plan = TilePlan(tuple(gt.shape), (1, 8, 8), (1, 16, 16))
+    tiles = plan.gather(pred).unsqueeze(1)
+    canvas, ps = plan.stitch_with_psnr(tiles, gt.unsqueeze(-1))
+    assert torch.equal(canvas[..., 0], pred)
+    assert maxabs(ps[:, 0].cpu().numpy(), g["ri_psnr"]) < 1e-3, (ps.cpu().numpy(), g["ri_psnr"])
+    # two channels, bigger frames, against the (golden-pinned) torch metric on the stitched canvas
+    rng = np.random.default_rng(2)
+    gt2 = torch.from_numpy(rng.standard_normal((2, 160, 224, 2)).astype(np.float32) * 3 + 1).cuda()
+    pr2 = 0.6 * gt2 + 0.4 * torch.from_numpy(rng.standard_normal((2, 160, 224, 2)).astype(np.float32)).cuda() - 0.3
+    plan2 = TilePlan((2, 160, 224), (1, 32, 32), (1, 64, 64))
+    tiles2 = torch.stack([plan2.gather(pr2[..., c].contiguous()) for c in range(2)], dim=1)
+    canvas2, ps2 = plan2.stitch_with_psnr(tiles2, gt2)
+    assert torch.equal(canvas2, pr2)
+    for c in range(2):
+        ref = RangeInvariantPsnr(gt2[..., c], canvas2[..., c])
+        assert maxabs(ps2[:, c].cpu().numpy(), ref.cpu().numpy()) < 1e-3
+    _, ps3 = plan2.stitch_with_psnr(tiles2, gt2)
+    assert torch.equal(ps2, ps3)                                     # fixed reduction order: bitwise reproducible
+
+
+@pytest.mark.parametrize("nsteps", [1, 2])
+def test_time_predictor_refinement_batched(nsteps):
+    """N3 (core/psnr_based_t_refinement.py:14-57): TimePredictor -> per-tile start time -> both InDI samplers ->
+    RangeInvariantPsnr scan, batched (one loop per sampler with per-sample step tables) against the fixture the
+    reference's own classes produced sample by sample (oracle/gen_golden.py).  The reference draws its noise per
+    sample (indi_1 start, steps; indi_2 start, steps); the draws are replayed in that order."""
+    from diffsplitting_amd.core import psnr_based_t_refinement as R
+    from diffsplitting_amd.model.ddpm_modules.time_predictor import TimePredictor
+    from diffsplitting_amd.model.ddpm_modules.unet import UNet
+    from diffsplitting_amd.model.samplers import InDISampler
+    g = load_golden(f"refine_n{nsteps}")
+    k1 = [(k, tuple(s)) for k, s in json.loads(bytes(g["keys1"]).decode())]
+    k2 = [(k, tuple(s)) for k, s in json.loads(bytes(g["keys2"]).decode())]
+    kt = [(k, tuple(s)) for k, s in json.loads(bytes(g["keys_tp"]).decode())]
+    c = cases.UNET_CASES["joint_32"]["cfg"]
+
+    def sampler(keys, seed):
+        net = UNet(in_channel=1, out_channel=1, inner_channel=c["inner_channel"], norm_groups=c["norm_groups"],
+                   channel_mults=c["channel_mults"], attn_res=c["attn_res"], res_blocks=c["res_blocks"], image_size=32)
+        s = InDISampler(net, 32, channels=1, out_channel=1, conditional=False, val_schedule_opt={"n_timestep": nsteps}).cuda()
+        s.load_state_dict(synth_state_dict(keys, seed), strict=True)
+        s.set_new_noise_schedule({"n_timestep": nsteps}, "cuda")
+        return s
+
+    i1, i2 = sampler(k1, 1), sampler(k2, 2)
+    tp = TimePredictor(**cases.TIME_PRED_CFG).cuda()
+    tp.load_state_dict(synth_state_dict(kt, 0), strict=True)
+    inp = cases.make_cond("time_pred")
+    B = inp.shape[0]
+    # the reference's draw sequence: for b: [i1 start, i1 steps..., i2 start, i2 steps...]
+    torch.manual_seed(cases.LOOP_SEED)
+    seq = {}
+    for b in range(B):
+        for name in ("i1", "i2"):
+            seq[(name, b)] = [torch.randn(1, 1, 32, 32) for _ in range(1 + nsteps)]
+
+    def source_for(name):
+        order = [seq[(name, b)][k] for b in range(B) for k in range(1 + nsteps)]   # the batched sampler asks per sample
+        it = iter(order)
+        return lambda shape: next(it)
+
+    i1.noise_source, i2.noise_source = source_for("i1"), source_for("i2")
+    t_hat = R.get_time_prediction_from_classifier(inp, tp)
+    assert maxabs(t_hat.cpu().numpy(), g["pred_t"]) <= FP32_TOL
+    pred1, pred2 = R.get_channel_estimates(inp, i1, i2, tp, num_timesteps=nsteps)
+    assert pred1.shape == g["pred1"].shape
+    assert maxabs(pred1, g["pred1"]) <= FP32_TOL and maxabs(pred2, g["pred2"]) <= FP32_TOL, (maxabs(pred1, g["pred1"]), maxabs(pred2, g["pred2"]))
+    i1.noise_source, i2.noise_source = source_for("i1"), source_for("i2")
+    per_sample_t, concensus_t = R.estimate_time_using_PSNR(inp, i1, i2, tp, num_timesteps=nsteps)
+    assert np.allclose(per_sample_t, g["per_sample_t"]) and abs(concensus_t - float(g["concensus_t"])) < 1e-9
+    # MMSE over repeats with device noise: runs batched, finite, and averages (cells 60-62 of the notebook)
+    i1.noise_source = i2.noise_source = None
+    m1, m2 = R.get_channel_estimates(inp, i1, i2, tp, num_timesteps=nsteps, mmse_count=3)
+    assert m1.shape == pred1.shape and np.isfinite(m1).all() and np.isfinite(m2).all()
+    assert maxabs(m1, g["pred1"]) < 0.2                                 # e = 0.01 noise: close to the single estimate

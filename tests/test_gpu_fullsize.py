@@ -162,18 +162,11 @@ def _sr3_loop(eng, sch, cond, draws, dev):
 def test_reduced_precision_loop_psnr(sched, shape, dev):
     """The headline dtype over WHOLE loops: bf16 / fp16 operands and activation storage for every step, identical
     injected noise, PSNR of the final images against the fp32 oracle loop (incl. the full 2000-step schedule)."""
-    sd, _ = golden_state_dict("loop_sr3_lin_8")
-    case = cases.UNET_CASES["sr3_tiny"]
-    sch = cases.SCHEDULES[sched]
-    g = torch.Generator().manual_seed(3)
-    cond = torch.randn(shape, generator=g)
-    rec = DrawRecorder(77)
-    osd = {"denoise_fn." + k: v for k, v in sd.items()}
-    _, full = samplers.sr3_p_sample_loop(osd, case["cfg"], samplers.gaussian_schedule(sch), cond, randn=rec,
-                                         return_full=True)
+    from tests.gpu_util import oracle_sr3_loop_tiny
+    sd, case, sch, cond, draws, full = oracle_sr3_loop_tiny(sched, shape)
     for dt in ("bf16", "f16"):
         eng = build_engine(case["cfg"], "sr3", sd, dtype=dt)
-        x = _sr3_loop(eng, sch, cond, rec.draws, dev)
+        x = _sr3_loop(eng, sch, cond, draws, dev)
         p = psnr(full.numpy(), x.numpy())
         print(f"\n{sched} ({sch['n_timestep']} steps) {dt}: PSNR of the final images vs the fp32 oracle loop = {p:.1f} dB, "
               f"max-abs {maxabs(x, full):.3e}")

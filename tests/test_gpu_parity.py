@@ -250,17 +250,10 @@ def test_joint_indi_two_streams(dev):
 def test_sr3_2000_steps_tiny(dev):
     """The full 2000-step schedule of sr_sr3_16_128 on the tiny UNet: drift stays under
     1e-3 with injected noise (re-association noise ~2e-6 over 2000 steps)."""
-    sd, _ = golden_state_dict("loop_sr3_lin_8")
-    case = cases.UNET_CASES["sr3_tiny"]
-    sch = cases.SCHEDULES["sr3_2000"]
-    g = torch.Generator().manual_seed(3)
-    cond = torch.randn((1, 3, 16, 16), generator=g)
-    rec = DrawRecorder(77)
-    osd = {"denoise_fn." + k: v for k, v in sd.items()}
-    _, full = samplers.sr3_p_sample_loop(osd, case["cfg"], samplers.gaussian_schedule(sch), cond, randn=rec,
-                                         return_full=True)
+    from tests.gpu_util import oracle_sr3_loop_tiny
+    sd, case, sch, cond, draws, full = oracle_sr3_loop_tiny("sr3_2000", (1, 3, 16, 16))
     eng = build_engine(case["cfg"], "sr3", sd)
-    x, _ = _sr3_engine_run(eng, sch, cond, rec.draws, dev, True)
+    x, _ = _sr3_engine_run(eng, sch, cond, draws, dev, True)
     print(f"\n2000 steps: max|hip-oracle| = {maxabs(x, full):.3e}")
     assert maxabs(x, full) <= FP32_TOL
 
