@@ -1491,6 +1491,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
     DSX_STAMP(4 + p);
   }
 
+  // the next image-resident conv's weight slices -> this XCD's L2 (its workgroups with the same label need them)
+  const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.x, gridDim.x, tid, 512);
   // ---- the 8 partial sums meet in LDS: part[w][mb][r][lane]
   __syncthreads();
   DSX_STAMP(12);
@@ -1555,6 +1557,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
       a.stat_part[((size_t)b * a.Cout + nb * 32 + ch) * 2 + k] = t;
     }
   }
+  l2_prefetch_retire(a.pf, pf_acc);
   DSX_STAMP(15);
 }
 

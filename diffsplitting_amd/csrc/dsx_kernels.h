@@ -8,6 +8,47 @@
 namespace dsx {
 
 // ---------------------------------------------------------------------------
+// L2 weight prefetch for the NEXT conv launch.  A conv's weight stream is read once per step and comes from HBM
+// (196 MB of weights per step do not stay in the 32 MB of L2); a wave can keep ~18 KiB of it in flight, so at HBM
+// latency the stream, not the MFMAs, paces the small-map layers.  The launch in front of a conv (its k_gn_finalize, or
+// the previous image-resident conv) therefore touches the 128-byte lines of the weight slices that the conv's
+// workgroups on the same XCD will read, so that they wait in that XCD's L2.  Workgroups are dealt round-robin over the 8 XCDs: blocks with equal
+// (linear id % 8) share an L2, and the consumer kernels key their N slices on that same label.  Placement only
+// affects speed: a different dispatch order makes the prefetch useless, never wrong.
+//   slices : `nslices` consecutive ranges of `slice_bytes` at `base`
+//   label x needs slice x % nslices when nslices < 8 (8 % nslices == 0), else every slice s with s % 8 == x
+// The loads are ordinary (compiler-counted) loads whose values are OR-ed into a word that is stored through `sink`
+// at the end of the kernel; `sink` is always nullptr, so nothing is ever stored, but the loads cannot be dropped
+// and no register is overwritten behind the compiler's back.
+// ---------------------------------------------------------------------------
+struct PrefetchArgs {
+  const void* base;       // nullptr: nothing to prefetch
+  unsigned slice_bytes;
+  int nslices;
+  unsigned* sink;         // always nullptr
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned l2_prefetch(const PrefetchArgs& pf, unsigned lin_block, unsigned nblocks_total, int tid, int nthreads) {
+  unsigned acc = 0u;
+  if (pf.base == nullptr || pf.nslices <= 0) return acc;
+  const unsigned label = lin_block & 7u, j = lin_block >> 3, n8 = (nblocks_total + 7u) >> 3;
+  const unsigned lines = pf.slice_bytes >> 7;            // whole 128-byte lines (slices are multiples of 1 KiB)
+  const unsigned per = (lines + n8 - 1u) / n8, l0 = j * per;
+  const unsigned l1 = l0 + per < lines ? l0 + per : lines;
+  const int s0 = pf.nslices < 8 ? (int)(label % (unsigned)pf.nslices) : (int)label;
+  const int sstep = pf.nslices < 8 ? pf.nslices : 8;     // nslices < 8: exactly one slice
+  for (int sl = s0; sl < pf.nslices; sl += sstep) {
+    const char* b = (const char*)pf.base + (size_t)sl * pf.slice_bytes;
+    for (unsigned l = l0 + (unsigned)tid; l < l1; l += (unsigned)nthreads) acc |= *(const unsigned*)(b + (size_t)l * 128);
+  }
+  return acc;
+}
+__device__ __forceinline__ void l2_prefetch_retire(const PrefetchArgs& pf, unsigned acc) {
+  if (pf.sink != nullptr) *pf.sink = acc;                 // never taken: keeps the prefetch loads alive
+}
+#endif
+
+// ---------------------------------------------------------------------------
 // Fused conv:  out = conv_{KSxKS, stride S}( act( gn(x) ) ) + bias + film + resid
 //   x is the channel-concatenation of up to two NHWC fp32 tensors (skip
 //   connections are never materialised), optionally nearest-upsampled x2.
@@ -55,6 +96,7 @@ struct ConvArgs {
   const void* gn_part1; int gn_nchunk1, gn_pf32_1;
   const float* gn_gamma; const float* gn_beta;
   int gn_groups; float gn_eps;
+  PrefetchArgs pf;        // weight slices of the next conv launch (see l2_prefetch)
   int ksplit;             // split-K slices (1 = none); slice s writes raw sums to out + s*slab_stride
   int groups_per_split;   // channel groups per slice
   long long slab_stride;  // elements between slabs
@@ -119,6 +161,7 @@ struct GnFinArgs {
   float eps;
   float* scale;          // [B][C0+C1]
   float* shift;
+  PrefetchArgs pf;       // weight slices of the conv this GroupNorm feeds (see l2_prefetch)
 };
 hipError_t launch_gn_finalize(const GnFinArgs& a, hipStream_t st);
 

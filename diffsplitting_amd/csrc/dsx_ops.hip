@@ -112,6 +112,8 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
   // fixed assignment + fixed butterfly order -> bitwise reproducible
   const int b = blockIdx.x, g = blockIdx.y;
   const int lane = threadIdx.x;
+  // first, so that they fly together with this launch's own loads: the consumer conv's weight slices -> this XCD's L2
+  const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, lane, 64);
   const int C = a.C0 + a.C1;
   const int cpg = C / a.groups;
   const int c_lo = g * cpg;
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
     a.scale[(size_t)b * C + c] = sc;
     a.shift[(size_t)b * C + c] = a.beta[c] - meanf * sc;
   }
+  l2_prefetch_retire(a.pf, pf_acc);
 }
 
 hipError_t launch_gn_finalize(const GnFinArgs& a, hipStream_t st) {

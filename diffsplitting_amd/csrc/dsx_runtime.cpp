@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -558,6 +559,11 @@ struct dsx_exec {
   std::vector<OpInfo> op_info;                               // parallel to ops
   int conv_ordinal = 0;
   bool overflow = false;
+  // L2 weight prefetch (l2_prefetch in dsx_kernels.h): the k_gn_finalize launch planned for the conv being planned,
+  // and the previous image-resident conv, receive the weight slices of that conv (filled in once its kernel and
+  // tiling are known)
+  std::shared_ptr<PrefetchArgs> pending_gn_pf;
+  std::shared_ptr<PrefetchArgs> prev_img_pf;
   unsigned long long* stamp_buf = nullptr;
   std::vector<StatInfo> stats;
   // fixed buffers
@@ -687,7 +693,8 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   static const std::vector<int> ws_wide1 = tile_order("DSX_TILES_WS_WIDE_1X1", {TILE_128x128, TILE_64x128});
   const std::vector<int>& ws_wide = ks == 1 ? ws_wide1 : ws_wide3;
   static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_256x64, TILE_128x64, TILE_64x64});
-  if (ws_on && stride == 1 && a.stage_mode == 0) {
+  static const int ws_1x1 = getenv("DSX_WS_1X1") ? atoi(getenv("DSX_WS_1X1")) : 1;
+  if (ws_on && (ks != 1 || ws_1x1) && stride == 1 && a.stage_mode == 0) {
     for (int tile : (is_wide ? ws_wide : ws_narrow)) {
       if (!tile_geometry(dtype, tile, ks, stride, a, c)) continue;
       if (conv_ws_lds_bytes(dtype, tile, ks, c) == 0) continue;
@@ -745,6 +752,7 @@ static void plan_stats(dsx_exec* ex, const Tensor& t);
 static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* t1, float** scale, float** shift);
 
 static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
+  ex->pending_gn_pf.reset();
   ConvArgs a{};
   a.src0 = s.x0.p; a.C0 = s.x0.C;
   a.src1 = s.x1.C ? s.x1.p : nullptr; a.C1 = s.x1.C;
@@ -836,8 +844,13 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       a.stat_part = (float*)si.part;
     }
     if (ex->sizing) return DSX_OK;
+    static const int pf_on = getenv("DSX_PREFETCH") ? atoi(getenv("DSX_PREFETCH")) : 1;
+    const PrefetchArgs mine{a.wpack, (unsigned)((size_t)a.kchunks * ks * ks * 2 * 1024), a.nblocks, nullptr};   // one slice per N block
+    if (pf_on && ex->prev_img_pf) *ex->prev_img_pf = mine;      // the previous image-resident conv warms the L2s for this one
+    auto pf = std::make_shared<PrefetchArgs>(PrefetchArgs{nullptr, 0u, 0, nullptr});
+    ex->prev_img_pf = pf;
     add_op(ex, DSX_OP_CONV_MFMA, fmt("conv%dx%d %d->%d @%dx%d img", ks, ks, (int)cin, a.Cout, a.Ho, a.Wo), flops, bytes,
-           [=](hipStream_t st) { return launch_conv_img(dtype, ks, a, st); });
+           [=](hipStream_t st) { ConvArgs b = a; b.pf = *pf; return launch_conv_img(dtype, ks, b, st); });
     return DSX_OK;
   }
   if (s.gn) {   // every other kernel takes the per-channel scale / shift a k_gn_finalize launch prepares
@@ -850,7 +863,8 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   ex->launches++;
   static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
   static const int ws_enabled = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
-  const bool use_ws = mfma_ok && ws_enabled && stride == 1 && a.stage_mode == 0 && a.ksplit == 1 &&
+  static const int ws_1x1_enabled = getenv("DSX_WS_1X1") ? atoi(getenv("DSX_WS_1X1")) : 1;
+  const bool use_ws = mfma_ok && ws_enabled && (ks != 1 || ws_1x1_enabled) && stride == 1 && a.stage_mode == 0 && a.ksplit == 1 &&
                       conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
   if (fuse_stats && s.want_stats && mfma_ok && (use_ws ? conv_ws_fuses_stats(tile) : conv_tile_fuses_stats(tile)) &&
       a.ksplit == 1 && a.tb_log2 == 0 &&
@@ -906,6 +920,15 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         if (w.ws_wg_per_n > a.m_tiles) w.ws_wg_per_n = (a.m_tiles + unit - 1) / unit * unit;
       }
       if (use_ws) {
+        // this conv's k_gn_finalize launch pulls the weight slices into the L2 of the XCD group that will read them
+        // (k_conv_ws keys its N tile on blockIdx % 8 in exactly these two cases)
+        static const int pf_on = getenv("DSX_PREFETCH") ? atoi(getenv("DSX_PREFETCH")) : 1;
+        const int NT = a.n_tiles;
+        const bool keyed = (NT <= 8 && 8 % NT == 0 && w.ws_wg_per_n % (8 / NT) == 0) || (NT % 8) == 0;
+        if (pf_on && ex->pending_gn_pf && keyed) {
+          const size_t wblock = (size_t)a.kchunks * ks * ks * 2 * 1024;     // bytes of one 32-channel N block's fragments
+          *ex->pending_gn_pf = PrefetchArgs{a.wpack, (unsigned)(wblock * (ti.BN / 32)), NT, nullptr};
+        }
         add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
                [=](hipStream_t st) { return launch_conv_ws(dtype, tile, ks, w, st); });
       } else {
@@ -963,8 +986,10 @@ static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* 
   a.B = ex->B; a.groups = ex->m->cfg.norm_groups; a.count = (double)t0.H * t0.W;
   a.gamma = g.gamma; a.beta = g.beta; a.eps = 1e-5f;
   a.scale = *scale; a.shift = *shift;
+  auto pf = std::make_shared<PrefetchArgs>(PrefetchArgs{nullptr, 0u, 0, nullptr});
+  ex->pending_gn_pf = pf;    // plan_conv fills it in once it has chosen the consumer's kernel and tiling
   add_op(ex, DSX_OP_GN_FINALIZE, fmt("gn_finalize C=%d", C), 0.0, 0.0,
-         [=](hipStream_t st) { return launch_gn_finalize(a, st); });
+         [=](hipStream_t st) { GnFinArgs b = a; b.pf = *pf; return launch_gn_finalize(b, st); });
 }
 
 static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tensor* x1, Tensor& y) {
@@ -1024,6 +1049,8 @@ static int build_plan(dsx_exec* ex) {
   ex->ws_used = 0;
   ex->ops.clear();
   ex->conv_ordinal = 0;
+  ex->prev_img_pf.reset();
+  ex->pending_gn_pf.reset();
   ex->op_info.clear();
   ex->stats.clear();
   ex->launches = 0;
