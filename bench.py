@@ -123,13 +123,16 @@ def roofline(eng, ex, dtype, iters=3):
     assert nl.value == len(conv)
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    traffic = None   # HBM bytes per conv launch from rocprofv3 PMC passes (profiles/traffic.json), not measurable live
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    # HBM bytes per conv launch and MFMA-busy fraction come from rocprofv3 PMC passes of this same command
+    # (tools/measure_r02.sh -> profiles/r02_counters.json): counters cannot be read live from inside the process
+    traffic, mfma_busy = None, None
+    cpath = os.path.join(ROOT, "profiles", "r02_counters.json")
+    if os.path.exists(cpath) and dtype == "bf16":
         try:
-            traffic = json.load(open(tpath)).get(dtype)
+            cj = json.load(open(cpath))
+            traffic, mfma_busy = cj.get("hbm_bytes_per_conv_launch"), cj.get("mfma_busy_frac_conv")
         except Exception:
-            traffic = None
+            traffic, mfma_busy = None, None
     by_kind = {}
     for r in rows:
         by_kind[r[0]] = by_kind.get(r[0], 0.0) + r[4]
@@ -146,8 +149,9 @@ def roofline(eng, ex, dtype, iters=3):
     for r in top:
         tf = r[2] / (r[4] * 1e-3) / 1e12 if r[4] > 0 else 0.0
         print(f"[bench]   {r[4]:8.4f} ms  {tf:8.1f} TF/s  {r[1]}", file=sys.stderr)
-    return {"bound": "mfma", "kernel": "k_conv_ws / k_conv_mfma (fused GN+Swish+conv implicit GEMM; all conv launches of one UNet forward)",
+    return {"bound": "mfma", "kernel": "k_conv_ws / k_conv_mfma / k_conv_img / k_conv_first (fused GN+Swish+conv implicit GEMM on MFMA; all conv launches of one UNet forward)",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "mfma_busy": mfma_busy,
             "launches": len(conv), "avg_launch_ms": conv_ms / max(1, len(conv)),
             "conv_ms_per_step": conv_ms, "conv_ms_per_step_eager_events": conv_ms_eager,
             "all_kernels_ms_per_step_eager_events": total_ms}
