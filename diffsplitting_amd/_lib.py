@@ -50,6 +50,9 @@ SIGNATURES = {
     "dsx_model_set_param": (_i, [_vp, _i, _vp, _i64]),
     "dsx_model_set_posenc_freq": (_i, [_vp, _vp, _i]),
     "dsx_model_finalize": (_i, [_vp, _i]),
+    "dsx_model_packed_bytes": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
+    "dsx_model_export_packed": (_i, [_vp, _vp, C.c_size_t]),
+    "dsx_model_finalize_packed": (_i, [_vp, _i, _vp, C.c_size_t]),
     "dsx_model_flops": (C.c_double, [_vp, _i, _i]),
     "dsx_exec_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
     "dsx_exec_destroy": (None, [_vp]),

@@ -392,80 +392,97 @@ static void pack_first(const float* w, int cout, int cin, int dtype, std::vector
   }
 }
 
-extern "C" int dsx_model_finalize(dsx_model* m, int dtype) {
-  if (!m) return fail(DSX_ERR_INVALID, "null model");
-  if (dtype != DSX_DTYPE_F32 && dtype != DSX_DTYPE_BF16 && dtype != DSX_DTYPE_F16) return fail(DSX_ERR_INVALID, "bad dtype");
-  for (int i = 0; i < (int)m->params.size(); ++i) {
-    if (m->params[i].set || i == m->p_invfreq) continue;  // inv_freq is derived below if absent
-    return fail(DSX_ERR_MISSING, "parameter %s was never set", m->params[i].name.c_str());
-  }
-  const int inner = m->cfg.inner_channel;
-  if (m->cfg.with_time_emb) {
-    if (m->cfg.flavour == DSX_FLAVOUR_DDPM) {
-      Param& p = m->params[m->p_invfreq];
-      if (p.set) m->freq = p.host;
-      else {  // ddpm unet.py:22-26
-        m->freq.resize(inner / 2);
-        for (int k = 0; k < inner / 2; ++k) m->freq[k] = expf((float)(2 * k) * (float)(-log(10000.0) / inner));
-      }
-    } else if (!m->freq_set) {  // sr3 unet.py:24-28
-      m->freq.resize(inner / 2);
-      for (int k = 0; k < inner / 2; ++k)
-        m->freq[k] = expf((float)(-log(1e4)) * ((float)k / (float)(inner / 2)));
-    }
-  }
-  // ---- build one host image of everything that goes to the device
-  std::vector<char> img;
-  auto reserve = [&](size_t bytes) {
-    size_t off = (img.size() + 255) & ~(size_t)255;
-    img.resize(off + bytes);
-    return off;
-  };
+namespace {
+// One host image of everything the model keeps on the device (fragment-ordered conv weights, biases, GroupNorm
+// affine parameters, time-embedding MLP, stacked FiLM linears).  With `write` false only the layout is computed
+// (offsets and the total size): dsx_model_finalize_packed uploads a cached image into exactly this layout.
+struct DevImage {
+  bool write;
+  std::vector<char> buf;
+  size_t size = 0;
   struct Fix { void** dst; size_t off; };
   std::vector<Fix> fix;
-  auto put_f32 = [&](const std::vector<float>& v, float** dst) {
-    size_t off = reserve(v.size() * 4);
-    memcpy(img.data() + off, v.data(), v.size() * 4);
-    fix.push_back({(void**)dst, off});
+  size_t reserve(size_t bytes) {
+    const size_t off = (size + 255) & ~(size_t)255;
+    size = off + bytes;
+    if (write) buf.resize(size);
+    return off;
+  }
+  void put(const void* src, size_t bytes, void** dst) {
+    const size_t off = reserve(bytes);
+    if (write) memcpy(buf.data() + off, src, bytes);
+    fix.push_back({dst, off});
+  }
+};
+}  // namespace
+
+// layout (and, with img.write, contents) of the device image for `dtype`; the conv geometry is stored in the model
+static int build_image(dsx_model* m, int dtype, DevImage& img) {
+  const int inner = m->cfg.inner_channel;
+  if (img.write) {
+    for (int i = 0; i < (int)m->params.size(); ++i) {
+      if (m->params[i].set || i == m->p_invfreq) continue;  // inv_freq is derived below if absent
+      return fail(DSX_ERR_MISSING, "parameter %s was never set", m->params[i].name.c_str());
+    }
+    if (m->cfg.with_time_emb) {
+      if (m->cfg.flavour == DSX_FLAVOUR_DDPM) {
+        Param& p = m->params[m->p_invfreq];
+        if (p.set) m->freq = p.host;
+        else {  // ddpm unet.py:22-26
+          m->freq.resize(inner / 2);
+          for (int k = 0; k < inner / 2; ++k) m->freq[k] = expf((float)(2 * k) * (float)(-log(10000.0) / inner));
+        }
+      } else if (!m->freq_set) {  // sr3 unet.py:24-28
+        m->freq.resize(inner / 2);
+        for (int k = 0; k < inner / 2; ++k)
+          m->freq[k] = expf((float)(-log(1e4)) * ((float)k / (float)(inner / 2)));
+      }
+    }
+  }
+  auto put_param = [&](int pi, float** dst) {   // one fp32 parameter as it is
+    img.put(img.write ? m->params[pi].host.data() : nullptr, (size_t)m->params[pi].numel() * 4, (void**)dst);
   };
   auto put_conv = [&](ConvW& c) {
     if (c.pw < 0) return;
+    conv_geometry(c.cout, c.cin, c.ks, dtype, c.kchunks, c.nblocks);
     std::vector<char> pk;
-    pack_conv(m->params[c.pw].host.data(), c.cout, c.cin, c.ks, dtype, pk, c.kchunks, c.nblocks);
-    size_t off = reserve(pk.size());
-    memcpy(img.data() + off, pk.data(), pk.size());
-    fix.push_back({&c.pack, off});
+    size_t bytes = (size_t)c.nblocks * c.kchunks * c.ks * c.ks * 2 * 64 * 16;
+    if (img.write) { pack_conv(m->params[c.pw].host.data(), c.cout, c.cin, c.ks, dtype, pk, c.kchunks, c.nblocks); bytes = pk.size(); }
+    img.put(pk.data(), bytes, &c.pack);
     if (c.ks == 3 && c.cin <= 7) {
       std::vector<char> pf;
-      pack_first(m->params[c.pw].host.data(), c.cout, c.cin, dtype, pf);
-      size_t off2 = reserve(pf.size());
-      memcpy(img.data() + off2, pf.data(), pf.size());
-      fix.push_back({&c.pack_first, off2});
+      size_t fb = (size_t)((c.cout + 31) / 32) * (dtype == DSX_DTYPE_F32 ? 32 * 64 * 4 : 4 * 64 * 16);
+      if (img.write) { pack_first(m->params[c.pw].host.data(), c.cout, c.cin, dtype, pf); fb = pf.size(); }
+      img.put(pf.data(), fb, &c.pack_first);
     }
-    if (c.pb >= 0) put_f32(m->params[c.pb].host, &c.bias);
+    if (c.pb >= 0) put_param(c.pb, &c.bias);
     if (m->want_naive) {
-      std::vector<float> nv((size_t)c.cout * c.ks * c.ks * c.cin);
-      const float* w = m->params[c.pw].host.data();
-      for (int n = 0; n < c.cout; ++n)
-        for (int ci = 0; ci < c.cin; ++ci)
-          for (int t = 0; t < c.ks * c.ks; ++t)
-            nv[((size_t)n * c.ks * c.ks + t) * c.cin + ci] = w[((size_t)n * c.cin + ci) * c.ks * c.ks + t];
-      put_f32(nv, &c.naive);
+      std::vector<float> nv;
+      if (img.write) {
+        nv.resize((size_t)c.cout * c.ks * c.ks * c.cin);
+        const float* w = m->params[c.pw].host.data();
+        for (int n = 0; n < c.cout; ++n)
+          for (int ci = 0; ci < c.cin; ++ci)
+            for (int t = 0; t < c.ks * c.ks; ++t)
+              nv[((size_t)n * c.ks * c.ks + t) * c.cin + ci] = w[((size_t)n * c.cin + ci) * c.ks * c.ks + t];
+      }
+      img.put(nv.data(), (size_t)c.cout * c.ks * c.ks * c.cin * 4, (void**)&c.naive);
     }
   };
   auto put_gn = [&](GnW& g) {
     if (g.pg < 0) return;
-    put_f32(m->params[g.pg].host, &g.gamma);
-    put_f32(m->params[g.pb].host, &g.beta);
+    put_param(g.pg, &g.gamma);
+    put_param(g.pb, &g.beta);
   };
-  std::vector<float> wf((size_t)m->F * inner), bf(m->F);
+  std::vector<float> wf, bf;
+  if (img.write) { wf.resize((size_t)m->F * inner); bf.resize(m->F); }
   for (auto& md : m->mods) {
     put_conv(md.conv);
     put_gn(md.gn1); put_gn(md.gn2); put_gn(md.gna);
     put_conv(md.conv1); put_conv(md.conv2);
     if (md.has_res) put_conv(md.res);
     if (md.attn) { put_conv(md.qkv); put_conv(md.out); }
-    if (md.film_off >= 0) {
+    if (md.film_off >= 0 && img.write) {
       memcpy(wf.data() + (size_t)md.film_off * inner, m->params[md.film.pw].host.data(),
              (size_t)md.cout * inner * 4);
       memcpy(bf.data() + md.film_off, m->params[md.film.pb].host.data(), (size_t)md.cout * 4);
@@ -476,22 +493,67 @@ extern "C" int dsx_model_finalize(dsx_model* m, int dtype) {
     }
   }
   if (m->cfg.with_time_emb) {
-    put_f32(m->freq, &m->d_freq);
-    put_f32(m->params[m->t1.pw].host, &m->d_w1);
-    put_f32(m->params[m->t1.pb].host, &m->d_b1);
-    put_f32(m->params[m->t2.pw].host, &m->d_w2);
-    put_f32(m->params[m->t2.pb].host, &m->d_b2);
-    put_f32(wf, &m->d_wf);
-    put_f32(bf, &m->d_bf);
+    img.put(m->freq.data(), (size_t)(inner / 2) * 4, (void**)&m->d_freq);
+    put_param(m->t1.pw, &m->d_w1);
+    put_param(m->t1.pb, &m->d_b1);
+    put_param(m->t2.pw, &m->d_w2);
+    put_param(m->t2.pb, &m->d_b2);
+    img.put(wf.data(), (size_t)m->F * inner * 4, (void**)&m->d_wf);
+    img.put(bf.data(), (size_t)m->F * 4, (void**)&m->d_bf);
   }
+  return DSX_OK;
+}
+
+static int upload_image(dsx_model* m, int dtype, const DevImage& img, const void* bytes) {
   if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }
-  HIP_TRY(hipMalloc((void**)&m->arena, img.size()));
-  HIP_TRY(hipMemcpy(m->arena, img.data(), img.size(), hipMemcpyHostToDevice));
-  m->arena_bytes = img.size();
-  for (auto& f : fix) *f.dst = m->arena + f.off;
+  HIP_TRY(hipMalloc((void**)&m->arena, img.size));
+  HIP_TRY(hipMemcpy(m->arena, bytes, img.size, hipMemcpyHostToDevice));
+  m->arena_bytes = img.size;
+  for (auto& f : img.fix) *f.dst = m->arena + f.off;
   m->dtype = dtype;
   m->finalized = true;
   return DSX_OK;
+}
+
+static bool dtype_ok(int dtype) { return dtype == DSX_DTYPE_F32 || dtype == DSX_DTYPE_BF16 || dtype == DSX_DTYPE_F16; }
+
+extern "C" int dsx_model_finalize(dsx_model* m, int dtype) {
+  if (!m) return fail(DSX_ERR_INVALID, "null model");
+  if (!dtype_ok(dtype)) return fail(DSX_ERR_INVALID, "bad dtype");
+  DevImage img;
+  img.write = true;
+  int rc = build_image(m, dtype, img);
+  if (rc) return rc;
+  return upload_image(m, dtype, img, img.buf.data());
+}
+
+// ---- packed-weight cache (the one-time repack of a *_gen.pth, model/model.py:153-166): export the device image of a
+// finalized model, and finalize a fresh model straight from such an image (no parameters set, no repacking)
+extern "C" int dsx_model_packed_bytes(dsx_model* m, int dtype, size_t* bytes) {
+  if (!m || !bytes || !dtype_ok(dtype)) return fail(DSX_ERR_INVALID, "bad argument");
+  DevImage img;
+  img.write = false;
+  int rc = build_image(m, dtype, img);
+  if (rc) return rc;
+  *bytes = img.size;
+  return DSX_OK;
+}
+extern "C" int dsx_model_export_packed(const dsx_model* m, void* host_buf, size_t capacity) {
+  if (!m || !host_buf) return fail(DSX_ERR_INVALID, "null argument");
+  if (!m->finalized) return fail(DSX_ERR_STATE, "finalize the model before exporting its packed image");
+  if (capacity < m->arena_bytes) return fail(DSX_ERR_INVALID, "buffer of %zu bytes < %zu", capacity, m->arena_bytes);
+  HIP_TRY(hipMemcpy(host_buf, m->arena, m->arena_bytes, hipMemcpyDeviceToHost));
+  return DSX_OK;
+}
+extern "C" int dsx_model_finalize_packed(dsx_model* m, int dtype, const void* host_img, size_t bytes) {
+  if (!m || !host_img || !dtype_ok(dtype)) return fail(DSX_ERR_INVALID, "bad argument");
+  DevImage img;
+  img.write = false;
+  int rc = build_image(m, dtype, img);
+  if (rc) return rc;
+  if (img.size != bytes)
+    return fail(DSX_ERR_INVALID, "packed image of %zu bytes does not fit this model / dtype (%zu expected)", bytes, img.size);
+  return upload_image(m, dtype, img, host_img);
 }
 
 extern "C" double dsx_model_flops(const dsx_model* m, int H, int W) {
@@ -1214,8 +1276,10 @@ extern "C" int dsx_exec_time_kind(dsx_exec* ex, int kind, int iters, float* ms_p
   if (!ex || !ms_per_replay || iters < 1) return fail(DSX_ERR_INVALID, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (!st) return fail(DSX_ERR_INVALID, "dsx_exec_time_kind needs a non-default stream (stream capture)");
+  // kind >= 0: the launches of that kind; -1: every launch of the forward; <= -2: every launch except kind (-kind - 2)
+  auto selected = [&](int k) { return kind >= 0 ? k == kind : (kind == -1 ? true : k != -kind - 2); };
   int n = 0;
-  for (auto& oi : ex->op_info) n += oi.kind == kind ? 1 : 0;
+  for (auto& oi : ex->op_info) n += selected(oi.kind) ? 1 : 0;
   if (launches) *launches = n;
   if (n == 0) { *ms_per_replay = 0.f; return DSX_OK; }
   hipGraph_t graph = nullptr;
@@ -1224,7 +1288,7 @@ extern "C" int dsx_exec_time_kind(dsx_exec* ex, int kind, int iters, float* ms_p
   HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   hipError_t err = hipSuccess;
   for (size_t i = 0; i < ex->ops.size() && err == hipSuccess; ++i)
-    if (ex->op_info[i].kind == kind) err = ex->ops[i](st);
+    if (selected(ex->op_info[i].kind)) err = ex->ops[i](st);
   hipError_t e2 = hipStreamEndCapture(st, &graph);
   if (err != hipSuccess || e2 != hipSuccess || !graph) {
     if (graph) (void)hipGraphDestroy(graph);

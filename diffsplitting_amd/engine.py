@@ -7,6 +7,7 @@ only; all sampling compute happens inside ``libdsx.so``.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -140,6 +141,50 @@ class UNetEngine:
             self._drop_execs()
             check(lib.dsx_model_finalize(self._h, code))
             self._finalized_dtype = code
+
+    # ---- packed-weight cache (N4: the repack next to `*_gen.pth`, model/model.py:153-166) -------------------
+    _PACK_MAGIC = b"DSXPACK2"
+
+    def _pack_header(self, dtype_code_, key):
+        import hashlib
+        cfg_bytes = bytes(memoryview(self.cfg))                      # the UNet configuration (ctypes struct)
+        h = hashlib.sha256(cfg_bytes + bytes([dtype_code_, lib.dsx_abi_version()]) + str(key).encode()).digest()
+        return self._PACK_MAGIC + h
+
+    def save_packed(self, path, key):
+        """Write the device image of the finalized model (fragment-ordered weights etc.) to ``path``."""
+        if self._finalized_dtype is None:
+            raise DsxError("finalize() before save_packed()")
+        n = C.c_size_t()
+        check(lib.dsx_model_packed_bytes(self._h, self._finalized_dtype, C.byref(n)))
+        buf = np.empty(n.value, dtype=np.uint8)
+        check(lib.dsx_model_export_packed(self._h, buf.ctypes.data_as(C.c_void_p), n.value))
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(self._pack_header(self._finalized_dtype, key))
+            buf.tofile(f)
+        os.replace(tmp, path)
+
+    def finalize_from_packed(self, path, dtype, key):
+        """Finalize from a cached image if ``path`` holds one for this configuration, dtype, ABI and ``key`` (the
+        checkpoint's hash); returns False (and does nothing) otherwise.  No parameter needs to be set."""
+        _lib.require_gpu()
+        code = dtype_code(dtype)
+        if not os.path.exists(path):
+            return False
+        n = C.c_size_t()
+        check(lib.dsx_model_packed_bytes(self._h, code, C.byref(n)))
+        hdr = self._pack_header(code, key)
+        if os.path.getsize(path) != len(hdr) + n.value:
+            return False
+        with open(path, "rb") as f:
+            if f.read(len(hdr)) != hdr:
+                return False
+            buf = np.fromfile(f, dtype=np.uint8, count=n.value)
+        self._drop_execs()
+        check(lib.dsx_model_finalize_packed(self._h, code, buf.ctypes.data_as(C.c_void_p), n.value))
+        self._finalized_dtype = code
+        return True
 
     def flops(self, H, W):
         return float(lib.dsx_model_flops(self._h, int(H), int(W)))

@@ -33,6 +33,9 @@ class EngineUNet(nn.Module):
         self._eng = engine.UNetEngine(self.cfg, self.flavour)
         self.compute_dtype = "f32"
         self._synced = None
+        # packed-weight cache (set by DDPM.load_network): file prefix and the checkpoint's hash
+        self.pack_cache = None          # (path_prefix, key) or None
+        self.pack_cache_hit = None      # True / False after the last engine() sync that consulted the cache
         g = torch.Generator().manual_seed(0)
         self._ref_names = list(self._eng.param_names)
         for name, shape in zip(self._eng.param_names, self._eng.param_shapes):
@@ -73,6 +76,7 @@ class EngineUNet(nn.Module):
                 continue
             with torch.no_grad():
                 t.copy_(src)
+        self.pack_cache = None      # new weights: a cache, if any, is re-attached by DDPM.load_network
         if strict:
             for key in state_dict:
                 if key.startswith(prefix) and key[len(prefix):] not in mine:
@@ -87,8 +91,23 @@ class EngineUNet(nn.Module):
         """The finalized ``UNetEngine`` with the module's current weights."""
         fp = self._fingerprint()
         if self._synced != fp:
-            self._eng.load_state_dict(self._tensors())
-            self._eng.finalize(self.compute_dtype)
+            hit = False
+            if self.pack_cache is not None:
+                prefix, key = self.pack_cache
+                path = f"{prefix}.{self.compute_dtype}.dsxpack"
+                hit = self._eng.finalize_from_packed(path, self.compute_dtype, key)
+                if not hit:
+                    self._eng.load_state_dict(self._tensors())
+                    self._eng._finalized_dtype = None
+                    self._eng.finalize(self.compute_dtype)
+                    try:
+                        self._eng.save_packed(path, key)
+                    except OSError:
+                        pass                                   # read-only checkpoint directory: no cache
+                self.pack_cache_hit = hit
+            else:
+                self._eng.load_state_dict(self._tensors())
+                self._eng.finalize(self.compute_dtype)
             self._synced = fp
         return self._eng
 

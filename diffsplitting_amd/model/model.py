@@ -78,5 +78,19 @@ class DDPM(BaseModel):
         load_path = self.opt["path"]["resume_state"] if self.opt["path"] else None
         if load_path is not None:
             logger.info("Loading pretrained model for G [{:s}] ...".format(load_path))
-            sd = torch.load("{}_gen.pth".format(load_path), map_location="cpu", weights_only=True)
+            gen_path = "{}_gen.pth".format(load_path)
+            sd = torch.load(gen_path, map_location="cpu", weights_only=True)
             self.netG.load_state_dict(sd, strict=(not self.opt["model"]["finetune_norm"]))
+            # packed-weight cache next to the checkpoint, keyed by the checkpoint's hash: the MFMA-fragment repack of
+            # every conv is done once per (checkpoint, dtype), later loads upload the cached image
+            import hashlib
+            h = hashlib.sha256()
+            with open(gen_path, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+            key = h.hexdigest()
+            k = 0
+            for m in self.netG.modules():
+                if hasattr(m, "pack_cache"):
+                    m.pack_cache = ("{}_gen.unet{}".format(load_path, k), key)
+                    k += 1

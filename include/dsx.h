@@ -86,6 +86,15 @@ int dsx_model_set_posenc_freq(dsx_model* m, const float* host_freq, int count);
 /* Repacks all weights into the kernels' layouts (MFMA fragment order, fp32 or
  * bf16) and uploads them to the current HIP device. */
 int dsx_model_finalize(dsx_model* m, int compute_dtype);
+/* Packed-weight cache: the repack of a checkpoint (model/model.py:153-166 loads `*_gen.pth`; the engine then
+ * reorders every conv into MFMA fragment order) is done once.  dsx_model_export_packed copies the device image of
+ * a finalized model to host memory (dsx_model_packed_bytes bytes for this model and dtype); dsx_model_finalize_packed
+ * finalizes a freshly created model of the same configuration straight from such an image: no dsx_model_set_param,
+ * no repacking.  The image layout depends on (configuration, dtype, DSX_ABI_VERSION): callers key their cache on
+ * those and on the checkpoint's hash. */
+int dsx_model_packed_bytes(dsx_model* m, int compute_dtype, size_t* bytes);
+int dsx_model_export_packed(const dsx_model* m, void* host_buf, size_t capacity);
+int dsx_model_finalize_packed(dsx_model* m, int compute_dtype, const void* host_image, size_t bytes);
 /* Algorithmic FLOPs (2*MAC of conv/linear/attention contractions) of one
  * forward of one image of H x W. */
 double dsx_model_flops(const dsx_model* m, int H, int W);
@@ -123,6 +132,8 @@ int dsx_exec_profile(dsx_exec* ex, int iters, float* ms_per_op, void* stream);
  * what `rocprofv3 --kernel-trace` sums for that kernel family inside the captured sampling step (the eager
  * per-launch times of dsx_exec_profile additionally contain the launch gaps). Inputs are whatever the
  * workspace holds; the timing of these kernels does not depend on the data. */
+/* kind >= 0: that kind only; -1: every launch of the forward; <= -2: every launch except kind (-kind - 2), so that
+ * time(-1) - time(-2 - k) is the time kind k takes INSIDE the forward (neighbouring launches warm its caches). */
 int dsx_exec_time_kind(dsx_exec* ex, int kind, int iters, float* ms_per_replay, int* launches, void* stream);
 /* diagnostics: in-kernel phase stamps (s_memtime) of the conv launch selected by DSX_STAMP_OP */
 int dsx_exec_read_stamps(dsx_exec* ex, unsigned long long* out128);

@@ -302,3 +302,36 @@ def test_time_predictor_refinement_batched(nsteps):
     m1, m2 = R.get_channel_estimates(inp, i1, i2, tp, num_timesteps=nsteps, mmse_count=3)
     assert m1.shape == pred1.shape and np.isfinite(m1).all() and np.isfinite(m2).all()
     assert maxabs(m1, g["pred1"]) < 0.2                                 # e = 0.01 noise: close to the single estimate
+
+
+def test_packed_weight_cache(tmp_path):
+    """N4: load_network (model/model.py:153-166) repacks a checkpoint once; the second load of the same `*_gen.pth`
+    uploads the cached image (keyed by the checkpoint hash, dtype, configuration, ABI) and computes bitwise the same."""
+    from diffsplitting_amd.model import create_model
+    from diffsplitting_amd.model.engine_unet import EngineUNet
+    sd, _ = golden_state_dict("loop_indi_n3_t1.0")
+    opt = _opt(_tiny_indi_section())
+    opt["path"]["checkpoint"] = str(tmp_path)
+    m1 = create_model(opt)
+    m1.netG.load_state_dict({"denoise_fn." + k: v for k, v in sd.items()})
+    m1.save_network(epoch=1, iter_step=10)
+    x = cases.make_cond("indi_loop").cuda()
+
+    def load():
+        o = _opt(_tiny_indi_section())
+        o["path"]["resume_state"] = str(tmp_path / "I10_E1")
+        m = create_model(o)
+        m.netG.e = 0.0
+        out = m.netG.inference(x, num_timesteps=2)
+        unet = [u for u in m.netG.modules() if isinstance(u, EngineUNet)][0]
+        return out, unet.pack_cache_hit
+
+    a, hit_a = load()
+    assert hit_a is False and (tmp_path / "I10_E1_gen.unet0.f32.dsxpack").exists()
+    b, hit_b = load()
+    assert hit_b is True and torch.equal(a, b)
+    # a different checkpoint under the same name must not reuse the image
+    sd2 = {k: v + 0.01 for k, v in m1.netG.state_dict().items()}
+    torch.save({k: v.cpu() for k, v in sd2.items()}, tmp_path / "I10_E1_gen.pth")
+    c, hit_c = load()
+    assert hit_c is False and not torch.equal(a, c)
