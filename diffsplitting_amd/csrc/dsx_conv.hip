@@ -1822,7 +1822,40 @@ int conv_lds_row(int ks, int stride, int tw_log2) {
   return rb;
 }
 
+// ---- two-chunk-per-group 3x3 variant (ConvArgs::cpg == 2): 64 input channels per staged group.  For the 64-channel
+// layers of the 128^2 level the whole K extent is one group: load + GroupNorm/Swish + one barrier + 36 MFMA steps +
+// epilogue, three workgroups per CU overlapping each other's phases, instead of the persistent kernel's per-group
+// hand-offs (which dominate when a tile has only two groups).
+int conv_lds_row_g2(int tw_log2) {
+  const int pixb = 64 * 2 + 16;
+  const int pw = ((1 << tw_log2) - 1) + 3;
+  int rb = (pw * pixb + 15) & ~15;
+  if (tw_log2 == 4) rb = (rb + 255) & ~255;
+  else if (tw_log2 == 3) { rb = (rb + 127) & ~127; if (((rb >> 7) & 1) == 0) rb += 128; }
+  return rb;
+}
+size_t conv_g2_lds_bytes(int tile, const ConvArgs& a) {
+  if (tile != TILE_128x64) return 0;
+  const ConvTileInfo ti = conv_tile_info(tile);
+  if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != ti.BM || a.tb_log2 != 0) return 0;
+  if (patch_pixels(3, 1, a) > 220 || a.lds_row != conv_lds_row_g2(a.tw_log2)) return 0;
+  if (a.kchunks % 2 || a.stage_mode != 0) return 0;
+  const int ph = ((1 << a.th_log2) - 1) + 3;
+  const size_t bufb = (size_t)ph * a.lds_row;
+  const size_t need = (a.kchunks / 2 > 1 ? 2 : 1) * bufb;     // a single group never touches the second buffer
+  return need <= 64 * 1024 ? need : 0;
+}
+template <typename DT> static hipError_t launch_g2(const ConvArgs* ap, size_t lds, hipStream_t st) {
+  constexpr TileCfg t = kTiles[TILE_128x64];
+  auto kern = k_conv_mfma<DT, t.MB, t.WM, t.WN, 3, 1, 2, 6, (220 * 8 + 255) / 256>;
+  if (!ap) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  dim3 grid((unsigned)(ap->m_tiles * ap->n_tiles * ap->ksplit));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, *ap);
+  return hipGetLastError();
+}
+
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a) {
+  if (a.cpg == 2 && ks == 3 && stride == 1) return conv_g2_lds_bytes(tile, a);
   if (tile < 0 || tile >= TILE_COUNT) return 0;
   if (!(ks == 1 || ks == 3) || !(stride == 1 || (stride == 2 && ks == 3 && tile == TILE_64x64))) return 0;
   const ConvTileInfo ti = conv_tile_info(tile);
@@ -1872,6 +1905,8 @@ static hipError_t launch_dt(int tile, int ks, int stride, const ConvArgs* a, siz
 hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& a, hipStream_t st) {
   const size_t lds = conv_lds_bytes(dtype, tile, ks, stride, a);
   if (lds == 0 || a.ksplit < 1 || a.n_tiles < 1) return hipErrorInvalidValue;
+  if (a.cpg == 2)
+    return dtype == 1 ? launch_g2<__bf16>(&a, lds, st) : dtype == 2 ? launch_g2<_Float16>(&a, lds, st) : launch_g2<float>(&a, lds, st);
   return dtype == 1 ? launch_dt<__bf16>(tile, ks, stride, &a, lds, st)
        : dtype == 2 ? launch_dt<_Float16>(tile, ks, stride, &a, lds, st)
                     : launch_dt<float>(tile, ks, stride, &a, lds, st);
@@ -1991,6 +2026,12 @@ hipError_t conv_init() {
             if (e != hipSuccess) return e;
           }
         }
+  {
+    hipError_t e = launch_g2<float>(nullptr, 0, nullptr);
+    if (e == hipSuccess) e = launch_g2<__bf16>(nullptr, 0, nullptr);
+    if (e == hipSuccess) e = launch_g2<_Float16>(nullptr, 0, nullptr);
+    if (e != hipSuccess) return e;
+  }
   for (int ks = 1; ks <= 3; ks += 2) {
     hipError_t e = launch_img_dt<float>(ks, nullptr, 0, nullptr);
     if (e == hipSuccess) e = launch_img_dt<__bf16>(ks, nullptr, 0, nullptr);

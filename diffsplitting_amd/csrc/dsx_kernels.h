@@ -84,6 +84,9 @@ struct ConvArgs {
   int tw_log2, th_log2, tb_log2;  // output tile = TB images x TH x TW pixels
   int tiles_x, tiles_y, m_tiles, n_tiles;
   int lds_row;            // LDS bytes per patch row (conv_lds_row)
+  int cpg;                // 0: the kernel family's default chunks per staged group (1 for 3x3, 2 for 1x1);
+                          // 2 with a 3x3: the two-chunk variant of k_conv_mfma (64 input channels per barrier: a
+                          // 64-channel layer is ONE group, no K loop)
   int ws_wg_per_n;        // warp-specialised kernel: persistent workgroups per N tile (0: k_conv_mfma)
   int xcd_bands;          // k_conv_ws: an XCD's workgroups take a contiguous band of M tiles (else round-robin)
   float* stat_part;       // fused GroupNorm partials [B][tiles_x*tiles_y*WM][Cout][2] (fp32) or nullptr
@@ -113,6 +116,9 @@ int conv_ws_tile_wm(int tile);          // k_conv_ws lays its waves out differen
 // input-channel chunks are staged in groups of this many (weights are packed/padded to it)
 int conv_chunk_multiple(int ks);
 int conv_lds_row(int ks, int stride, int tw_log2);
+// two-chunk-per-group 3x3 variant of k_conv_mfma (ConvArgs::cpg == 2), TILE_128x64 only
+int conv_lds_row_g2(int tw_log2);
+size_t conv_g2_lds_bytes(int tile, const ConvArgs& a);
 // LDS bytes needed by a launch; 0 if the geometry is not supported by `tile`
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a);
 hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& a, hipStream_t st);

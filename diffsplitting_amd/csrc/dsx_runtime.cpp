@@ -755,6 +755,30 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   static const std::vector<int> ws_wide1 = tile_order("DSX_TILES_WS_WIDE_1X1", {TILE_128x128, TILE_64x128});
   const std::vector<int>& ws_wide = ks == 1 ? ws_wide1 : ws_wide3;
   static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_256x64, TILE_128x64, TILE_64x64});
+  // Pass -1 (experiment, off: DSX_CPG2=1 enables it): few input channels at a large map (the 64-channel layers of the
+  // 128^2 level) on the two-chunk variant of k_conv_mfma: every 64 input channels are one staged group, three
+  // workgroups per CU overlap their load / MFMA / epilogue phases.  Measured slower than the persistent kernel
+  // (64->64 @128^2: 60 us vs 42 us), see DESIGN.md.
+  static const int g2_on = getenv("DSX_CPG2") ? atoi(getenv("DSX_CPG2")) : 0;
+  static const int g2_max_c = getenv("DSX_CPG2_MAXC") ? atoi(getenv("DSX_CPG2_MAXC")) : 64;
+  if (g2_on && ks == 3 && stride == 1 && a.Cout == 64 && a.stage_mode == 0 && a.kchunks % 2 == 0 &&
+      a.C0 % 64 == 0 && a.C1 % 64 == 0 && a.C0 + a.C1 <= g2_max_c) {
+    ConvArgs g = a;
+    const int tile = TILE_128x64;
+    const ConvTileInfo ti = conv_tile_info(tile);
+    const int TW = pow2_divisor(a.Wo, 16), TH = pow2_divisor(a.Ho, std::max(1, ti.BM / TW));
+    if (TW * TH == ti.BM) {
+      g.cpg = 2;
+      g.tw_log2 = ilog2(TW); g.th_log2 = ilog2(TH); g.tb_log2 = 0;
+      g.tiles_x = a.Wo / TW; g.tiles_y = a.Ho / TH;
+      g.m_tiles = g.tiles_x * g.tiles_y * a.B;
+      g.n_tiles = 1;
+      g.ksplit = 1; g.groups_per_split = a.kchunks / 2; g.slab_stride = 0;
+      g.lds_row = conv_lds_row_g2(g.tw_log2);
+      g.ablate = 0;
+      if (conv_g2_lds_bytes(tile, g) != 0 && g.m_tiles >= 512) { a = g; tile_out = tile; return true; }
+    }
+  }
   static const int ws_1x1 = getenv("DSX_WS_1X1") ? atoi(getenv("DSX_WS_1X1")) : 1;
   if (ws_on && (ks != 1 || ws_1x1) && stride == 1 && a.stage_mode == 0) {
     for (int tile : (is_wide ? ws_wide : ws_narrow)) {
@@ -926,8 +950,8 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
   static const int ws_enabled = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
   static const int ws_1x1_enabled = getenv("DSX_WS_1X1") ? atoi(getenv("DSX_WS_1X1")) : 1;
-  const bool use_ws = mfma_ok && ws_enabled && (ks != 1 || ws_1x1_enabled) && stride == 1 && a.stage_mode == 0 && a.ksplit == 1 &&
-                      conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
+  const bool use_ws = mfma_ok && a.cpg != 2 && ws_enabled && (ks != 1 || ws_1x1_enabled) && stride == 1 && a.stage_mode == 0 &&
+                      a.ksplit == 1 && conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
   if (fuse_stats && s.want_stats && mfma_ok && (use_ws ? conv_ws_fuses_stats(tile) : conv_tile_fuses_stats(tile)) &&
       a.ksplit == 1 && a.tb_log2 == 0 &&
       (a.Cout & 15) == 0 &&
@@ -994,7 +1018,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
                [=](hipStream_t st) { return launch_conv_ws(dtype, tile, ks, w, st); });
       } else {
-        add_op(ex, DSX_OP_CONV_MFMA, d, flops, bytes,
+        add_op(ex, DSX_OP_CONV_MFMA, a.cpg == 2 ? d + " g2" : d, flops, bytes,
                [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
       }
     }
