@@ -73,6 +73,7 @@ SIGNATURES = {
     "dsx_tile_plan": (_i64, [_pi64, _pi64, _pi64, _i, _pi64, _pi64, _i64]),
     "dsx_tile_regions": (_i, [_pi64, _pi64, _pi64, _i, _pi32, _i64]),
     "dsx_tiles_gather": (_i, [_vp, _pi64, _pi64, _pi64, _pi64, _i64, _vp, _vp]),
+    "dsx_tiles_gather_norm": (_i, [_vp, _vp, _pi64, _pi64, _pi64, _pi64, _i64, _f, _f, C.POINTER(C.c_double), _i, _vp, _vp, _vp]),
     "dsx_stitch": (_i, [_vp, _i64, _i, _i, _i, _pi32, _vp, _pi64, _vp]),
     "dsx_stitch_psnr_blocks": (_i, [_i, _i]),
     "dsx_stitch_psnr": (_i, [_vp, _i64, _i, _i, _i, _pi32, _vp, _pi64, _vp, _vp, _vp]),

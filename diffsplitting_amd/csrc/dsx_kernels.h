@@ -253,6 +253,10 @@ hipError_t launch_randn(float* out, long long n, unsigned long long seed, unsign
 hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw,
                                const int* starts /*dev [count][3]*/, long long count, float* tiles,
                                hipStream_t st);
+// crop + dataset normalisation fused (SplitDataset.__getitem__): norm = {mean_inp, std_inp, mean_t0, std_t0, mean_t1, std_t1}
+hipError_t launch_tiles_gather_norm(const float* f0, const float* f1, int H, int W, int ph, int pw, const int* starts,
+                                    long long count, float w0, float w1, const double norm[6], int from_norm_target,
+                                    float* tin, float* ttar, hipStream_t st);
 hipError_t launch_stitch(const float* tiles, long long count, int C, int ph, int pw,
                          const int* regions /*dev [count][8]*/, float* canvas, int H, int W,
                          hipStream_t st);

@@ -485,6 +485,49 @@ hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw
   return hipGetLastError();
 }
 
+// tile crop + the dataset's normalisation in one pass (SplitDataset.__getitem__, data/split_dataset.py:237-278):
+//   target_c = (frame_c - mean_target_c) / std_target_c                       (normalize_target, :199-201)
+//   input    = w0 * target_0 + w1 * target_1                                   (input_from_normalized_target)
+//            | ((w0 * frame_0 + w1 * frame_1) - mean_input) / std_input        (normalize_inp, :195-197)
+// in double, rounded to fp32 once, exactly as numpy does with its float64 statistics.
+struct GatherNormArgs {
+  const float* f0; const float* f1;
+  int H, W, ph, pw;
+  const int* starts;       // dev [count][3]
+  float w0, w1;
+  double mean_inp, std_inp, mt0, st0, mt1, st1;
+  int from_norm_target;
+  float* tin;              // (count, 1, ph, pw)
+  float* ttar;             // (count, 2, ph, pw)
+};
+__global__ void k_tiles_gather_norm(const GatherNormArgs a) {
+  const long long t = blockIdx.y;
+  const int n = a.starts[t * 3], y0 = a.starts[t * 3 + 1], x0 = a.starts[t * 3 + 2];
+  const int total = a.ph * a.pw;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int y = i / a.pw, x = i % a.pw;
+    const size_t src = ((size_t)n * a.H + (y0 + y)) * a.W + (x0 + x);
+    const float p0 = a.f0[src], p1 = a.f1[src];
+    const float t0 = (float)(((double)p0 - a.mt0) / a.st0), t1 = (float)(((double)p1 - a.mt1) / a.st1);
+    float in;
+    if (a.from_norm_target) in = __fadd_rn(__fmul_rn(a.w0, t0), __fmul_rn(a.w1, t1));
+    else in = (float)(((double)__fadd_rn(__fmul_rn(a.w0, p0), __fmul_rn(a.w1, p1)) - a.mean_inp) / a.std_inp);
+    a.tin[t * total + i] = in;
+    a.ttar[(t * 2) * total + i] = t0;
+    a.ttar[(t * 2 + 1) * total + i] = t1;
+  }
+}
+hipError_t launch_tiles_gather_norm(const float* f0, const float* f1, int H, int W, int ph, int pw, const int* starts,
+                                    long long count, float w0, float w1, const double norm[6], int from_norm_target,
+                                    float* tin, float* ttar, hipStream_t st) {
+  GatherNormArgs a{f0, f1, H, W, ph, pw, starts, w0, w1, norm[0], norm[1], norm[2], norm[3], norm[4], norm[5],
+                   from_norm_target, tin, ttar};
+  int gx = (ph * pw + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_tiles_gather_norm, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 __global__ void k_stitch(const float* __restrict__ tiles, int C, int ph, int pw,
                          const int* __restrict__ regions, float* __restrict__ canvas, int H, int W) {
   const long long t = blockIdx.y;

@@ -1753,3 +1753,34 @@ extern "C" int dsx_stitch_psnr(const float* tiles, int64_t count, int C, int ph,
   HIP_TRY(hipFree(d_reg));
   return DSX_OK;
 }
+
+// tiles of both channels cut out of device-resident frames AND normalised in the same pass: the batch source of tiled
+// prediction without the per-tile host crop + host->device copy of the reference's DataLoader(batch_size = 1)
+extern "C" int dsx_tiles_gather_norm(const float* frames0, const float* frames1, const int64_t data_shape[3],
+                                     const int64_t patch_shape[3], const int64_t* patch_start, const int64_t* tile_ids,
+                                     int64_t count, float w0, float w1, const double norm[6], int from_norm_target,
+                                     float* tiles_in, float* tiles_target, void* stream) {
+  if (!frames0 || !frames1 || !data_shape || !patch_shape || !patch_start || !norm || !tiles_in || !tiles_target || count < 0)
+    return fail(DSX_ERR_INVALID, "bad argument");
+  if (norm[1] == 0.0 || norm[3] == 0.0 || norm[5] == 0.0) return fail(DSX_ERR_INVALID, "zero standard deviation");
+  if (count == 0) return DSX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<int> starts((size_t)count * 3);
+  for (int64_t i = 0; i < count; ++i) {
+    const int64_t id = tile_ids ? tile_ids[i] : i;
+    for (int d = 0; d < 3; ++d) starts[i * 3 + d] = (int)patch_start[id * 3 + d];
+    if (starts[i * 3] < 0 || starts[i * 3] >= data_shape[0] || starts[i * 3 + 1] < 0 ||
+        starts[i * 3 + 1] + patch_shape[1] > data_shape[1] || starts[i * 3 + 2] < 0 ||
+        starts[i * 3 + 2] + patch_shape[2] > data_shape[2])
+      return fail(DSX_ERR_INVALID, "tile %lld lies outside the frames", (long long)id);
+  }
+  int* d_starts = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_starts, starts.size() * 4));
+  HIP_TRY(hipMemcpyAsync(d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(launch_tiles_gather_norm(frames0, frames1, (int)data_shape[1], (int)data_shape[2], (int)patch_shape[1],
+                                   (int)patch_shape[2], d_starts, count, w0, w1, norm, from_norm_target, tiles_in,
+                                   tiles_target, st));
+  HIP_TRY(hipFree(d_starts));
+  return DSX_OK;
+}

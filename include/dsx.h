@@ -231,6 +231,16 @@ int dsx_tiles_gather(const float* frames_dev, const int64_t data_shape[3],
                      const int64_t patch_shape[3], const int64_t* patch_start_host,
                      const int64_t* tile_ids_host, int64_t count, float* tiles_dev, void* stream);
 
+/* dsx_tiles_gather for both raw channels plus the dataset's normalisation, fused: replaces
+ * SplitDataset.__getitem__ (data/split_dataset.py:237-278: crop, normalize_target :199-201, weighted input,
+ * normalize_inp :195-197) for a whole batch of tiles.  norm = {mean_input, std_input, mean_target0, std_target0,
+ * mean_target1, std_target1} (float64, as compute_normalization_dict :29-74 returns them); from_norm_target selects
+ * input = w0*target0 + w1*target1 (input_from_normalized_target).  tiles_in (count,1,ph,pw), tiles_target (count,2,ph,pw). */
+int dsx_tiles_gather_norm(const float* frames0_dev, const float* frames1_dev, const int64_t data_shape[3],
+                          const int64_t patch_shape[3], const int64_t* patch_start_host, const int64_t* tile_ids_host,
+                          int64_t count, float w0, float w1, const double norm[6], int from_norm_target,
+                          float* tiles_in_dev, float* tiles_target_dev, void* stream);
+
 /* Pastes the valid region of `count` predicted tiles (count, C, ph, pw) into
  * the zero-initialised canvas (N,H,W,C), channel-last: replaces
  * stitch_predictions (data/tile_stitcher.py:10-81).  regions as from

@@ -335,3 +335,71 @@ def test_packed_weight_cache(tmp_path):
     torch.save({k: v.cpu() for k, v in sd2.items()}, tmp_path / "I10_E1_gen.pth")
     c, hit_c = load()
     assert hit_c is False and not torch.equal(a, c)
+
+
+def _numpy_item(ch0, ch1, loc, p, nd, w, from_norm_target):
+    """SplitDataset.__getitem__ (data/split_dataset.py:237-278) restated with numpy for one grid patch."""
+    n, y, x = loc
+    patch1 = ch0[n, y:y + p, x:x + p].astype(np.float32)[None]
+    patch2 = ch1[n, y:y + p, x:x + p].astype(np.float32)[None]
+    target = np.concatenate([patch1, patch2], axis=0)
+    target = ((target - nd["mean_target"].reshape(-1, 1, 1)) / nd["std_target"].reshape(-1, 1, 1)).astype(np.float32)
+    if from_norm_target:
+        inp = w[0] * target[0:1] + w[1] * target[1:2]
+    else:
+        inp = w[0] * patch1 + w[1] * patch2
+        inp = ((inp - nd["mean_input"]) / nd["std_input"]).astype(np.float32)
+    return {"input": inp, "target": target}
+
+
+def test_device_split_dataset_matches_numpy_restatement():
+    """N2: frames resident on the GPU; normalisation statistics (compute_normalization_dict :29-74: quantiles) on the
+    device equal numpy's; batches of normalised tiles from one HIP launch are bit-exact with __getitem__'s arithmetic."""
+    from diffsplitting_amd.data.split_dataset import (DataLocation, SplitDataset, SplitDatasetTiledPred,
+                                                      compute_normalization_dict)
+    rng = np.random.default_rng(11)
+    ch0 = (rng.gamma(2.0, 120.0, size=(3, 96, 160))).astype(np.float32)
+    ch1 = (rng.gamma(3.0, 60.0, size=(3, 96, 160))).astype(np.float32)
+    w = [1, 1]
+    nd = compute_normalization_dict({0: torch.from_numpy(ch0).cuda(), 1: torch.from_numpy(ch1).cuda()}, w, q_val=0.98)
+    assert nd["target0_max"] == float(np.quantile(ch0.reshape(-1), 0.98))     # numpy's linear-interpolation quantile
+    assert nd["target1_max"] == float(np.quantile(ch1.reshape(-1), 0.98))
+    assert abs(nd["input_max"] - float(np.quantile(ch0.reshape(-1) * 1 + ch1.reshape(-1) * 1, 0.98))) < 1e-9 * nd["input_max"]
+    for from_norm in (False, True):
+        ds = SplitDataset("Hagen", DataLocation(arrays=(ch0, ch1)), 32, max_qval=0.98, channel_weights=w,
+                          input_from_normalized_target=from_norm)
+        assert len(ds) == 3 * 3 * 5
+        ids = [0, 7, 14, 44]
+        batch = ds.tiles(ids)
+        assert batch["input"].shape == (4, 1, 32, 32) and batch["target"].shape == (4, 2, 32, 32)
+        for k, i in enumerate(ids):
+            ref = _numpy_item(ch0, ch1, ds.patch_location(i), 32, ds.get_normalization_dict(), w, from_norm)
+            assert np.array_equal(batch["target"][k].cpu().numpy(), ref["target"])
+            assert np.array_equal(batch["input"][k].cpu().numpy(), ref["input"])
+            item = ds[i]
+            assert np.array_equal(item["input"], ref["input"]) and np.array_equal(item["target"], ref["target"])
+    # upper_clip (:147-150) and the tiled-prediction subclass
+    dt = SplitDatasetTiledPred("Hagen", DataLocation(arrays=(ch0, ch1)), 64, grid_size=32, max_qval=0.98, upper_clip=True)
+    assert len(dt) == dt.plan.total == 3 * 2 * 4
+    c0 = np.clip(ch0, 0, dt.get_normalization_dict()["target0_max"])
+    c1 = np.clip(ch1, 0, dt.get_normalization_dict()["target1_max"])
+    ref = _numpy_item(c0, c1, dt.patch_location(5), 64, dt.get_normalization_dict(), [1, 1], False)
+    got = dt.tiles([5])
+    assert np.array_equal(got["target"][0].cpu().numpy(), ref["target"]) and np.array_equal(got["input"][0].cpu().numpy(), ref["input"])
+
+
+def test_reference_known_answer_through_the_device_dataset():
+    """tests/test_tiling_setup.py of the reference (arange frames, identity normalisation, every tile's own target as
+    the prediction, stitched == data exactly) with the device-resident dataset and the HIP stitch."""
+    from diffsplitting_amd.data.split_dataset import DataLocation, SplitDatasetTiledPred
+    from diffsplitting_amd.data.tile_stitcher import stitch_predictions
+    data = np.arange(5 * 512 * 512 * 2).reshape(5, 512, 512, 2).astype(np.float32)      # < 2^24: exact in fp32
+    nd = {"mean_input": 0, "std_input": 1, "mean_target": np.array([0, 0]), "std_target": np.array([1, 1]),
+          "target0_max": 1, "target1_max": 1, "input_max": 1}
+    ds = SplitDatasetTiledPred("Hagen", DataLocation(arrays=(data[..., 0], data[..., 1])), 256, grid_size=128,
+                               max_qval=0.98, upper_clip=False, normalization_dict=nd)
+    assert len(ds) == 45
+    preds = ds.tiles(range(len(ds)))["target"]
+    out = ds.plan.stitch(preds)
+    assert np.array_equal(out.cpu().numpy(), data)
+    assert np.array_equal(stitch_predictions(preds.cpu().numpy(), ds.tile_manager), data)
