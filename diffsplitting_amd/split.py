@@ -21,8 +21,7 @@ import torch
 
 from . import parallel
 from .core import logger as Logger
-from .core.psnr import RangeInvariantPsnr
-from .data.tiled_predict import predict_tiled
+from .data.split_dataset import DataLocation, SplitDatasetTiledPred
 from .model import create_model
 
 
@@ -75,29 +74,53 @@ def main(argv=None):
     else:
         n, h, w = (int(v) for v in args.synthetic.split(","))
         rng = np.random.default_rng(0)
-        frames = rng.random((n, h, w, 2), dtype=np.float32)
+        frames = (rng.random((n, h, w, 2), dtype=np.float32) * 1000.0).astype(np.float32)    # raw detector counts
         log.info("no --frames given: using synthetic frames %s", frames.shape)
-    # per-channel standardisation (stand-in for compute_normalization_dict, split_dataset.py:29-74)
-    mean = frames.mean(axis=(0, 1, 2), keepdims=True)
-    std = frames.std(axis=(0, 1, 2), keepdims=True)
-    target = torch.from_numpy((frames - mean) / std).to(dev)
-    inp = target.mean(dim=-1)                                         # notebook cell 23: input = target.mean(0)
-    patch = opt["datasets"]["val"]["patch_size"] if opt["datasets"] and opt["datasets"]["val"] else 512
-    patch = min(int(patch or 512), target.shape[1], target.shape[2])
+    # the validation dataset of split.get_datasets(opt, tiled_pred=True) (reference split.py:30-71) with the frames
+    # resident on the GPU: quantile normalisation (compute_normalization_dict), ShiftBoundary tiling, normalised
+    # tile batches cut by one HIP launch
+    dsopt = opt["datasets"] or {}
+    patch = (dsopt["val"] or {}).get("patch_size") if dsopt.get("val") else None
+    patch = int(patch or dsopt.get("patch_size") or 512)
+    patch = min(patch, frames.shape[1], frames.shape[2])
+    which = opt["model"]["which_model_G"]
+    val_set = SplitDatasetTiledPred("Hagen", DataLocation(arrays=(frames[..., 0], frames[..., 1])), patch,
+                                    grid_size=patch // 2, target_channel_idx=dsopt.get("target_channel_idx"),
+                                    max_qval=dsopt.get("max_qval") or 0.98, upper_clip=bool(dsopt.get("upper_clip")),
+                                    channel_weights=dsopt.get("channel_weights"), enable_transforms=False,
+                                    random_patching=False, input_from_normalized_target=(which == "joint_indi"),
+                                    device=dev)
+    plan = val_set.plan
+    ids = parallel.shard_ids(plan.total, rank, world)
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pred, plan = predict_tiled(netG, inp.contiguous(), patch, batch_tiles=args.batch_tiles,
-                               sampler_kwargs=dict(num_timesteps=n_steps))
+    outs, tars = [], []
+    for i in range(0, len(ids), args.batch_tiles):
+        batch = val_set.tiles(ids[i:i + args.batch_tiles])
+        netG.inference(batch["input"], continuous=False, num_timesteps=n_steps)
+        outs.append(netG.last_full_batch.clone())
+        tars.append(batch["target"])
+    C_out = netG.last_full_batch.shape[1] if outs else 1
+    local = torch.cat(outs) if outs else torch.zeros((0, C_out, patch, patch), device=dev)
+    ltar = torch.cat(tars) if tars else torch.zeros((0, 2, patch, patch), device=dev)
+    full = parallel.all_gather_tiles(local, plan.total)              # the path's only collective
+    gt_tiles = parallel.all_gather_tiles(ltar, plan.total)
+    gt = plan.stitch(gt_tiles)                                        # the normalised targets, (N,H,W,2)
+    if full.shape[1] == gt.shape[-1] and full.shape[1] <= 4:
+        pred, ps = plan.stitch_with_psnr(full, gt)                    # metric accumulated while pasting
+    else:
+        pred, ps = plan.stitch(full), None
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
         log.info("tiled prediction: %d tiles of %d^2, %d steps, %d GPU(s): %.3f s (%.1f tiles/s)",
                  plan.total, patch, n_steps, world, dt, plan.total / dt)
-        for c in range(min(pred.shape[-1], target.shape[-1])):
-            ps = RangeInvariantPsnr(target[..., c], pred[..., c])
-            log.info("channel %d: RangeInvariantPsnr %.2f +- %.2f dB (random-init weights unless a checkpoint "
-                     "was given in path.resume_state)", c, ps.mean().item(), ps.std().item() if len(ps) > 1 else 0.0)
+        if ps is not None:
+            for c in range(ps.shape[1]):
+                log.info("channel %d: RangeInvariantPsnr %.2f +- %.2f dB (random-init weights unless a checkpoint "
+                         "was given in path.resume_state)", c, ps[:, c].mean().item(),
+                         ps[:, c].std().item() if ps.shape[0] > 1 else 0.0)
     return pred
 
 

@@ -358,18 +358,24 @@ def test_device_split_dataset_matches_numpy_restatement():
     from diffsplitting_amd.data.split_dataset import (DataLocation, SplitDataset, SplitDatasetTiledPred,
                                                       compute_normalization_dict)
     rng = np.random.default_rng(11)
-    ch0 = (rng.gamma(2.0, 120.0, size=(3, 96, 160))).astype(np.float32)
-    ch1 = (rng.gamma(3.0, 60.0, size=(3, 96, 160))).astype(np.float32)
+    # square frames: the reference's grid formula (patch_location :215-225) divides and wraps by h // patch only
+    ch0 = (rng.gamma(2.0, 120.0, size=(3, 128, 128))).astype(np.float32)
+    ch1 = (rng.gamma(3.0, 60.0, size=(3, 128, 128))).astype(np.float32)
     w = [1, 1]
     nd = compute_normalization_dict({0: torch.from_numpy(ch0).cuda(), 1: torch.from_numpy(ch1).cuda()}, w, q_val=0.98)
-    assert nd["target0_max"] == float(np.quantile(ch0.reshape(-1), 0.98))     # numpy's linear-interpolation quantile
-    assert nd["target1_max"] == float(np.quantile(ch1.reshape(-1), 0.98))
-    assert abs(nd["input_max"] - float(np.quantile(ch0.reshape(-1) * 1 + ch1.reshape(-1) * 1, 0.98))) < 1e-9 * nd["input_max"]
+    d0, d1 = ch0.reshape(-1).astype(np.float64), ch1.reshape(-1).astype(np.float64)
+    assert nd["target0_max"] == np.quantile(d0, 0.98)                          # numpy's linear-interpolation quantile
+    assert nd["target1_max"] == np.quantile(d1, 0.98)
+    assert nd["input_max"] == np.quantile(d0 * 1 + d1 * 1, 0.98) and isinstance(nd["mean_input"], np.float64)
+    # the reference's frames are integer-typed .tif counts: numpy then works in float64, exactly this path
+    i0, i1 = np.floor(ch0).astype(np.uint16), np.floor(ch1).astype(np.uint16)
+    ndi = compute_normalization_dict({0: torch.from_numpy(i0.astype(np.int32)).cuda(), 1: torch.from_numpy(i1.astype(np.int32)).cuda()}, w, q_val=0.98)
+    assert ndi["target0_max"] == np.quantile(i0.reshape(-1), 0.98) and ndi["target1_max"] == np.quantile(i1.reshape(-1), 0.98)
     for from_norm in (False, True):
         ds = SplitDataset("Hagen", DataLocation(arrays=(ch0, ch1)), 32, max_qval=0.98, channel_weights=w,
                           input_from_normalized_target=from_norm)
-        assert len(ds) == 3 * 3 * 5
-        ids = [0, 7, 14, 44]
+        assert len(ds) == 3 * 4 * 4
+        ids = [0, 7, 14, 47]
         batch = ds.tiles(ids)
         assert batch["input"].shape == (4, 1, 32, 32) and batch["target"].shape == (4, 2, 32, 32)
         for k, i in enumerate(ids):
@@ -380,7 +386,7 @@ def test_device_split_dataset_matches_numpy_restatement():
             assert np.array_equal(item["input"], ref["input"]) and np.array_equal(item["target"], ref["target"])
     # upper_clip (:147-150) and the tiled-prediction subclass
     dt = SplitDatasetTiledPred("Hagen", DataLocation(arrays=(ch0, ch1)), 64, grid_size=32, max_qval=0.98, upper_clip=True)
-    assert len(dt) == dt.plan.total == 3 * 2 * 4
+    assert len(dt) == dt.plan.total == 3 * 3 * 3
     c0 = np.clip(ch0, 0, dt.get_normalization_dict()["target0_max"])
     c1 = np.clip(ch1, 0, dt.get_normalization_dict()["target1_max"])
     ref = _numpy_item(c0, c1, dt.patch_location(5), 64, dt.get_normalization_dict(), [1, 1], False)
