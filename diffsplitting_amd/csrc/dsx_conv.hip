@@ -1453,6 +1453,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
       }
     }
   }
+  // the next image-resident conv's weight slices -> this XCD's L2 (its workgroups with the same label need them): issued
+  // behind this kernel's own first loads, a whole kernel duration ahead of their use
+  const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.x, gridDim.x, tid, 512);
   DSX_STAMP(2);
   __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): the zero fill and the aff table are in LDS
   convert_store(0, raw0);
@@ -1491,8 +1494,6 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
     DSX_STAMP(4 + p);
   }
 
-  // the next image-resident conv's weight slices -> this XCD's L2 (its workgroups with the same label need them)
-  const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.x, gridDim.x, tid, 512);
   // ---- the 8 partial sums meet in LDS: part[w][mb][r][lane]
   __syncthreads();
   DSX_STAMP(12);
