@@ -37,10 +37,24 @@
 // hipcc (ROCm 7.2) fails in its spill path ("Illegal instruction detected: Operand has incorrect register class
 // V_CMP_NE_U32_e32 0, $src_private_base"); the same happens for a 64 x 256 tile (MB 2, WM 1, WN 4, NB 2).
 #ifndef DSX_PRE_RESID_EXPR
-#define DSX_PRE_RESID_EXPR (NB == 1 && MB <= 2)
+#define DSX_PRE_RESID_EXPR (NB == 1 && MB <= 2)   // (MB 4 with 16-bit storage fits the registers but measured 3 % slower)
 #endif
 #ifndef DSX_PF
 #define DSX_PF 2
+#endif
+#ifndef DSX_EPI_PRIO_COND
+#define DSX_EPI_PRIO_COND false
+#endif
+#ifndef DSX_STAMP_CVT_COND
+#define DSX_STAMP_CVT_COND (tiC == 2 && gC == 0)   // which item the loader-conversion stamps 120-123 record (diagnostic builds)
+#endif
+// 1 x 1 convs: weight fragments in flight per wave.  A group is only 4 steps (8-16 MFMAs), so a ring of one group
+// (round 1) exposed a whole L2 round trip per group: 1800-2500 cycles for 256 cycles of MFMA work.
+#ifndef DSX_RING_1X1_NB1
+#define DSX_RING_1X1_NB1 16
+#endif
+#ifndef DSX_RING_1X1_NB2
+#define DSX_RING_1X1_NB2 4
 #endif
 #ifndef DSX_LOADER_PRIO
 #define DSX_LOADER_PRIO 1
@@ -738,7 +752,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   [[maybe_unused]] constexpr bool IS_BF16 = sizeof(DT) == 2;
   constexpr int RAWB = NIT * LT * 16;           // one raw ring slot
   constexpr int NSLOT = P + 1;
-  static_assert(NSTEP % D == 0, "ring depth must divide the steps per group");
+  static_assert(D <= NSTEP ? NSTEP % D == 0 : (D % NSTEP == 0 && D / NSTEP <= 8), "ring depth divides the steps per group, or is a multiple of them");
   static_assert(WM * WN == 4 && P * NIT < 64, "4 compute waves; vmcnt is 6 bits");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -917,44 +931,61 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       const unsigned dst = lds0 + buf * BUFB;
       // the wait, then empty volatile asms that every read's result passes through: volatile asms keep their
       // order, so no use of a result can be scheduled above the wait
-      DSX_STAMP_T(120, tid == 256 && tiC == 2 && gC == 0);
+      DSX_STAMP_T(120, tid == 256 && DSX_STAMP_CVT_COND);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int q = 0; q < 2 * NA; ++q) asm volatile("" : "+v"(av[q]));
 #pragma unroll
       for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rv[it]));
-      DSX_STAMP_T(121, tid == 256 && tiC == 2 && gC == 0);
+      DSX_STAMP_T(121, tid == 256 && DSX_STAMP_CVT_COND);
       float sc[CPU], sh[CPU];
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
         sc[4 * q] = av[q].x; sc[4 * q + 1] = av[q].y; sc[4 * q + 2] = av[q].z; sc[4 * q + 3] = av[q].w;
         sh[4 * q] = av[NA + q].x; sh[4 * q + 1] = av[NA + q].y; sh[4 * q + 2] = av[NA + q].z; sh[4 * q + 3] = av[NA + q].w;
       }
+      // one uniform branch around the whole unit loop (a branch per unit keeps the units' arithmetic from interleaving):
+      // residual / attention-output 1 x 1 convs and the upsampling convs have no GroupNorm / Swish in front and copy
+      // (1 x 1 only: in the 3 x 3 instantiations the extra branch cost the GroupNorm layers 3-4 %, more than the four
+      // upsampling convs gained)
+      const bool plain = KS == 1 && !(gnF || a.swish);
+      if (plain) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        if (loff[it] >= 0) {
-          float v[CPU];
-          Unit<DT>::unpack(__builtin_bit_cast(uint4, rv[it]), v);
-          // the arithmetic runs in every lane; padding pixels (and channels past C) are forced to exactly 0
-          // afterwards with one mask per packed register (padded AFTER the activation, as the reference does)
+        for (int it = 0; it < NIT; ++it) {
+          if (loff[it] >= 0) {
+            uint4 w = __builtin_bit_cast(uint4, rv[it]);
+            const unsigned keep = ((edge[it] & flagsF) == 0 && cF < C) ? 0xffffffffu : 0u;
+            w.x &= keep; w.y &= keep; w.z &= keep; w.w &= keep;
+            lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, w));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          if (loff[it] >= 0) {
+            float v[CPU];
+            Unit<DT>::unpack(__builtin_bit_cast(uint4, rv[it]), v);
+            // the arithmetic runs in every lane; padding pixels (and channels past C) are forced to exactly 0
+            // afterwards with one mask per packed register (padded AFTER the activation, as the reference does)
 #ifndef DSX_ABL_CVT   // -DDSX_ABL_CVT: timing experiment, loaders skip the GroupNorm / Swish arithmetic (results wrong)
-          if (gnF) {
+            if (gnF) {
 #pragma unroll
-            for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
-          }
-          if (a.swish) {
+              for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
+            }
+            if (a.swish) {
 #pragma unroll
-            for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
-          }
+              for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
+            }
 #endif
-          if (it == NIT - 1) { asm volatile("" :: "v"(v[0]), "v"(v[CPU - 1])); DSX_STAMP_T(122, tid == 256 && tiC == 2 && gC == 0); }
-          uint4 w = Unit<DT>::pack(v);
-          const unsigned keep = ((edge[it] & flagsF) == 0 && cF < C) ? 0xffffffffu : 0u;
-          w.x &= keep; w.y &= keep; w.z &= keep; w.w &= keep;
-          lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, w));
+            if (it == NIT - 1) { asm volatile("" :: "v"(v[0]), "v"(v[CPU - 1])); DSX_STAMP_T(122, tid == 256 && DSX_STAMP_CVT_COND); }
+            uint4 w = Unit<DT>::pack(v);
+            const unsigned keep = ((edge[it] & flagsF) == 0 && cF < C) ? 0xffffffffu : 0u;
+            w.x &= keep; w.y &= keep; w.z &= keep; w.w &= keep;
+            lds_write_b128_asm(dst + loff[it], __builtin_bit_cast(f32x4_t, w));
+          }
         }
       }
-      DSX_STAMP_T(123, tid == 256 && tiC == 2 && gC == 0);
+      DSX_STAMP_T(123, tid == 256 && DSX_STAMP_CVT_COND);
     };
     // wait until the DMAs of the item to fetch have landed; `young` = younger items that may stay in flight
     auto wait_young = [&](int young) __attribute__((always_inline)) {
@@ -1154,131 +1185,26 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   int g = 0, ti = 0, aslot = 0;   // aslot == ti % 3
   constexpr int PF = NB == 2 ? 1 : DSX_PF;         // operand fragments are read PF steps ahead of their MFMAs (a step is NB x longer)
   static_assert(PF < NSTEP && PF * MB <= 15, "lgkmcnt is 4 bits");
-  for (int v = 0; v < total; ++v) {
-    unsigned aaddr[MB][KS];                   // LDS byte address of the fragment rows in this item's image
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int dy = 0; dy < KS; ++dy) aaddr[mb][dy] = lds0 + (v & 1) * BUFB + abase[mb][dy];
-    f32x4_t fb[PF + 1][MB];
-    auto read_step = [&](auto sc) __attribute__((always_inline)) {
-      constexpr int s = decltype(sc)::value;
-      constexpr int kTapSteps = TAPS * 2;
-      constexpr int cg = s / kTapSteps, tap = (s >> 1) % TAPS, fs = s & 1;
-      constexpr int dy = tap / KS, dx = tap % KS;
-      constexpr int imm = dx * PIXB + cg * 64 + fs * 32;
-      static_assert(imm < 65536, "ds offset field");
-#ifndef DSX_ABL_L   // -DDSX_ABL_L: timing experiment, LDS operand reads off (results wrong)
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) lds_read_frag<imm>(fb[s % (PF + 1)][mb], aaddr[mb][dy]);
-#else
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) touch_frag(fb[s % (PF + 1)][mb], aaddr[mb][dy]);
-#endif
-    };
-    static_for<PF>(read_step);
-    static_for<NSTEP>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      const WFrag bcur = bq[s % D];
-#ifndef DSX_ABL_W   // -DDSX_ABL_W: timing experiment, weight stream off (results wrong)
-      bq[s % D] = load_b();
-#endif
-      if constexpr (s + PF < NSTEP) read_step(std::integral_constant<int, s + PF>{});
-      constexpr int ahead = (NSTEP - 1 - s < PF ? NSTEP - 1 - s : PF) * MB;   // younger reads that may stay in flight
-      constexpr int cb = s % (PF + 1);
-      if constexpr (MB == 1) wait_frags<ahead>(fb[cb][0]);
-      else if constexpr (MB == 2) wait_frags<ahead>(fb[cb][0], fb[cb][1]);
-      else wait_frags<ahead>(fb[cb][0], fb[cb][1], fb[cb][2], fb[cb][3]);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          acc[mb][nb] = mfma_step<DT>(bcur.v[nb], fb[cb][mb], acc[mb][nb]);
-        }
-    });
-    DSX_STAMP_T(1 + 3 * v, tid == 0 && v < 20);
-    ws_barrier();   // the loaders may now overwrite this image; the next one is complete
-    DSX_STAMP_T(2 + 3 * v, tid == 0 && v < 20);
-    if (++g < G) continue;
-    g = 0;
-
-    // ---- tile finished: epilogue (+ fused statistics).  Accumulator register r of a lane is channel
-    //      16 * lh + r of the wave's 32-channel block, for the lane's pixel (see store16).
-    // scale/shift of tile ti+3 -> LDS slot (ti+3) % 3 == ti % 3, whose use ended with tile ti
-    if (a.gn_scale != nullptr && ti + 3 < ntile && tid * 4 < C) {
-      float* dst = aff_base + (size_t)aslot * (AFFB / 4);
-      *(float4*)(dst + tid * 4) = affv[0];
-      *(float4*)(dst + C + tid * 4) = affv[1];
+  // The ring slot of step s of item v is (v * NSTEP + s) % D: static for D <= NSTEP; for a ring of RP groups the item
+  // loop is unrolled RP times (ring phase R = v % RP static in each copy).
+  constexpr int RP = D > NSTEP ? D / NSTEP : 1;
+  if constexpr (RP == 1) {
+    for (int v = 0; v < total; ++v) {
+      constexpr int R0 = 0;
+#define DSX_WS_ITEM_NEXT continue
+#include "dsx_conv_ws_item.inc"
+#undef DSX_WS_ITEM_NEXT
     }
-    // conv -> + (bias | FiLM incl. bias) -> + residual
-    const int rcur = PRE_RESID ? 0 : tile_pixel0(cur) * a.resid_ld;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        float rs[16];
-#pragma unroll
-        for (int q = 0; q < NR; ++q) {
-          float t[CPU];
-          uint4 rr = make_uint4(0u, 0u, 0u, 0u);
-          if constexpr (PRE_RESID) rr = residv[mb][nb][q];
-          else if (a.resid) rr = *(const uint4*)((const DT*)a.resid + (rcur + rrow[mb]) + 32 * nb + CPU * q);
-          Unit<DT>::unpack(rr, t);
-#pragma unroll
-          for (int j = 0; j < CPU; ++j) rs[CPU * q + j] = t[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 ta = addv[nb][j];
-          acc[mb][nb][4 * j + 0] = (acc[mb][nb][4 * j + 0] + ta.x) + rs[4 * j + 0];
-          acc[mb][nb][4 * j + 1] = (acc[mb][nb][4 * j + 1] + ta.y) + rs[4 * j + 1];
-          acc[mb][nb][4 * j + 2] = (acc[mb][nb][4 * j + 2] + ta.z) + rs[4 * j + 2];
-          acc[mb][nb][4 * j + 3] = (acc[mb][nb][4 * j + 3] + ta.w) + rs[4 * j + 3];
-        }
-      }
-    DSX_STAMP_T(61, tid == 0 && ti == 1);
-    // the operand registers are free again: fetch the next tile's (and the scale/shift of the tile three after it)
-    const TilePos done = cur;
-    ++ti;
-    if (++aslot == 3) aslot = 0;
-    cur = nxt; nxt = nn; nn = n3; tile_advance(n3);
-    if (ti < ntile) prefetch_epilogue(cur, ti + 3 < ntile, n3.b);
-
-    const int o0 = tile_pixel0(done) * a.out_ld;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      float s1[16], s2[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        float x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = acc[mb][nb][r];
-#ifndef DSX_ABL_EPI   // -DDSX_ABL_EPI: timing experiment, no output stores (results wrong)
-        store16<true>(a.out, (size_t)(o0 + orow[mb] + 32 * nb), x, Kind<DT>::value, 16);   // host: out is in the storage type
-#endif
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s1[r] += x[r]; s2[r] += x[r] * x[r]; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
-      }
-      if (do_stats) {
-        // lane (li & 15) holds register row16_fold_reg(li), summed over its 16 pixels; add the other row's copy
-        float w1 = row16_fold(s1, lane), w2 = row16_fold(s2, lane);
-        w1 += __shfl_xor(w1, 16, 64);
-        w2 += __shfl_xor(w2, 16, 64);
-        const int chunk = (done.ty * a.tiles_x + done.tx) * WM + wm;
-        const int nch = per_img * WM;
-        const int n = nbase + 32 * nb + row16_fold_reg(li);
-        if (li < 16) {
-          float* pp = a.stat_part + (((size_t)done.b * nch + chunk) * a.Cout + n) * 2;
-          pp[0] = w1; pp[1] = w2;
-        }
-      }
-    }
-    DSX_STAMP_T(62, tid == 0 && ti == 2);
-    DSX_STAMP_T(3 + 3 * v, tid == 0 && v < 20);
+  } else {
+    for (int v0 = 0; v0 < total; v0 += RP)
+      static_for<RP>([&](auto rc_) __attribute__((always_inline)) {
+        constexpr int R0 = decltype(rc_)::value * NSTEP;
+        const int v = v0 + decltype(rc_)::value;
+        if (v >= total) return;
+#define DSX_WS_ITEM_NEXT return
+#include "dsx_conv_ws_item.inc"
+#undef DSX_WS_ITEM_NEXT
+      });
   }
 }
 
@@ -1299,7 +1225,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 //   * the 8 partial accumulators meet in LDS (fixed order -> bitwise reproducible), the epilogue adds bias / FiLM /
 //     residual, stores, and emits the complete per-(image, channel) GroupNorm sums of the result (one partial row).
 // ===========================================================================================
-template <typename DT, int KS>
+template <typename DT, int KS, int NPH>
 __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
   constexpr int KC = Chunk<DT>::KC;
   constexpr int CPU = Unit<DT>::N;
@@ -1310,7 +1236,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
   constexpr int IMGB = PW * RB;
   constexpr int NSTEP = TAPS * 2;
   constexpr int D = NSTEP;                      // weight fragments in flight: a whole phase (latency, not bandwidth, bounds the stream)
-  constexpr int MAXP = 8;                       // phases (host: C <= 8 * 8 * KC)
+  constexpr int MAXP = NPH;                     // phases this instantiation is unrolled for (host: C <= NPH * 8 * KC)
+  constexpr bool ALLW = NPH == 2;               // two phases: every weight fragment of the wave is requested up front
   static_assert(NSTEP % D == 0, "ring depth divides the steps of a phase");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -1321,7 +1248,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
   const int C = a.C0 + a.C1;
   const int nphase = C / (8 * KC);
   unsigned char* img = lds + wave * (2 * IMGB);
-  float* aff = (float*)(lds + 8 * 2 * IMGB) + wave * (MAXP * 2 * KC);   // [phase][scale KC | shift KC]
+  float* aff = (float*)(lds + 8 * 2 * IMGB) + wave * (8 * 2 * KC);      // [phase][scale KC | shift KC]
 
   DSX_STAMP(0);
   // zero both buffers once: the halo border stays zero (the reference pads AFTER the activation)
@@ -1374,31 +1301,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
     }
   };
 
-  uint4 raw0[4], raw1[4];
-  load_raw(0, raw0);
-  if (nphase > 1) load_raw(1, raw1);
-
-  // ---- weight stream: fragments of (N block nb, chunk 8p + wave), NSTEP x 1 KiB per phase, flat over the phases
-  const unsigned char* wbase = (const unsigned char*)a.wpack + (size_t)nb * a.kchunks * (NSTEP * 1024) + lane * 16;
-  int pn = 0, sn = 0;                           // phase and step of the next fragment to prefetch
-  auto load_w = [&]() __attribute__((always_inline)) -> uint4 {   // unconditional: the caller stops at the last phase
-    const uint4 v = *(const uint4*)(wbase + ((size_t)(pn * 8 + wave) * NSTEP + sn) * 1024);
-    if (++sn == NSTEP) { sn = 0; ++pn; }
-    return v;
-  };
-  uint4 wq[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) wq[j] = load_w();
-  DSX_STAMP(1);
-
-  // ---- GroupNorm: scale / shift of this wave's channels of every phase (lanes = 64 consecutive channels).
-  // All loads of all phases are issued before the first use (one memory round trip, not one per phase).
+  // ---- GroupNorm operands first: vmcnt retires in order, so the producer's partial sums (and gamma / beta) issued
+  // ahead of the activation slices and the 18-fragment weight ring arrive first, and the finalize arithmetic runs
+  // under the weight stream's latency instead of behind it (it waited ~18k cycles for its operands the other way round).
+  // Branch-free loads (a "load or skip" branch per phase would make hipcc wait vmcnt(0) inside every branch):
+  // phases past the last re-read the last one, the element is fetched as two 8-byte halves for either partial type.
+  uint2 glo[MAXP], ghi[MAXP];
+  float gg[MAXP], gb[MAXP];
   if (a.has_gn) {
-    const int cpg = C / a.gn_groups;            // host: power of two <= 64, divides C0
-    // branch-free loads (a "load or skip" branch per phase would make hipcc wait vmcnt(0) inside every branch):
-    // phases past the last re-read the last one, the element is fetched as two 8-byte halves for either partial type
-    uint2 glo[MAXP], ghi[MAXP];
-    float gg[MAXP], gb[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
       const int pp = p < nphase ? p : nphase - 1;
@@ -1412,6 +1322,34 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
       ghi[p] = *(const uint2*)(e + 8);          // second half of a double2 (ignored for float partials; stays inside the workspace)
       gg[p] = a.gn_gamma[c]; gb[p] = a.gn_beta[c];
     }
+  }
+  uint4 raw0[4], raw1[4];
+  load_raw(0, raw0);
+  if (nphase > 1) load_raw(1, raw1);
+
+  // ---- weight stream: fragments of (N block nb, chunk 8p + wave), NSTEP x 1 KiB per phase, flat over the phases
+  const unsigned char* wbase = (const unsigned char*)a.wpack + (size_t)nb * a.kchunks * (NSTEP * 1024) + lane * 16;
+  int pn = 0, sn = 0;                           // phase and step of the next fragment to prefetch
+  auto load_w = [&]() __attribute__((always_inline)) -> uint4 {   // unconditional: the caller stops at the last phase
+    const uint4 v = *(const uint4*)(wbase + ((size_t)(pn * 8 + wave) * NSTEP + sn) * 1024);
+    if (++sn == NSTEP) { sn = 0; ++pn; }
+    return v;
+  };
+  uint4 wq[D], wq1[ALLW ? D : 1];
+#pragma unroll
+  for (int j = 0; j < D; ++j) wq[j] = load_w();
+  if constexpr (ALLW) {
+    if (nphase > 1) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) wq1[j] = load_w();
+    }
+  }
+  DSX_STAMP(1);
+
+  // ---- GroupNorm: scale / shift of this wave's channels of every phase (lanes = 64 consecutive channels).
+  // All loads of all phases were issued at the top (one memory round trip, not one per phase).
+  if (a.has_gn) {
+    const int cpg = C / a.gn_groups;            // host: power of two <= 64, divides C0
     double gs[MAXP], gq[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
@@ -1482,8 +1420,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
     static_for<NSTEP>([&](auto sc_) __attribute__((always_inline)) {
       constexpr int s = decltype(sc_)::value;
       constexpr int tap = s >> 1, fs = s & 1, dy = tap / KS, dx = tap % KS;
-      const uint4 wcur = wq[s % D];
-      if (more) wq[s % D] = load_w();            // uniform: the next phase's fragment into the slot just consumed
+      uint4 wcur = wq[s % D];
+      if constexpr (ALLW) {
+        if (p == 1) wcur = wq1[s % D];           // uniform
+      } else {
+        if (more) wq[s % D] = load_w();          // uniform: the next phase's fragment into the slot just consumed
+      }
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         const f32x4_t px = *(const f32x4_t*)(buf + abase[mb][dy] + dx * PIXB + fs * 32);
@@ -1581,14 +1523,25 @@ bool conv_img_applicable(int dtype, int ks, int stride, const ConvArgs& a, bool 
   }
   return true;
 }
-template <typename DT, int KS> static hipError_t launch_img_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
-  auto kern = k_conv_img<DT, KS>;
+template <typename DT, int KS, int NPH> static hipError_t launch_img_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
+  auto kern = k_conv_img<DT, KS, NPH>;
   if (!ap) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3((unsigned)(ap->B * ap->nblocks)), dim3(512), lds, st, *ap);
   return hipGetLastError();
 }
+template <typename DT, int KS> static hipError_t launch_img_ks(const ConvArgs* a, size_t lds, hipStream_t st) {
+  if (!a) {   // one-time attributes of every instantiation
+    hipError_t e = launch_img_one<DT, KS, 2>(a, lds, st);
+    if (e == hipSuccess) e = launch_img_one<DT, KS, 4>(a, lds, st);
+    if (e == hipSuccess) e = launch_img_one<DT, KS, 8>(a, lds, st);
+    return e;
+  }
+  const int nphase = (a->C0 + a->C1) / (8 * Chunk<DT>::KC);   // the unroll depth: the smallest instantiation that holds it
+  return nphase <= 2 ? launch_img_one<DT, KS, 2>(a, lds, st)
+       : nphase <= 4 ? launch_img_one<DT, KS, 4>(a, lds, st) : launch_img_one<DT, KS, 8>(a, lds, st);
+}
 template <typename DT> static hipError_t launch_img_dt(int ks, const ConvArgs* a, size_t lds, hipStream_t st) {
-  return ks == 3 ? launch_img_one<DT, 3>(a, lds, st) : launch_img_one<DT, 1>(a, lds, st);
+  return ks == 3 ? launch_img_ks<DT, 3>(a, lds, st) : launch_img_ks<DT, 1>(a, lds, st);
 }
 hipError_t launch_conv_img(int dtype, int ks, const ConvArgs& a, hipStream_t st) {
   const size_t lds = conv_img_lds(dtype, ks);
@@ -1974,7 +1927,8 @@ static hipError_t launch_ws_one(const ConvArgs* ap, size_t lds, hipStream_t st) 
     constexpr WsTileCfg t = ws_tile(TILE);
     constexpr int CPG = conv_cpg(KS);
     // weight ring, in steps: a full group for one N block per wave, half of it (same bytes, same time) for two
-    constexpr int D = KS == 1 ? 4 : ((t.NB == 2 || t.MB == 4) ? 6 : 18);   // (MB 4: four MFMAs per step, and the registers are needed)
+    // (1 x 1 with two N blocks per wave or MB 4: a deeper ring spills, and hipcc's spill path fails on this kernel)
+    constexpr int D = KS == 1 ? ((t.NB == 2 || t.MB == 4) ? DSX_RING_1X1_NB2 : DSX_RING_1X1_NB1) : ((t.NB == 2 || t.MB == 4) ? 6 : 18);   // (MB 4: four MFMAs per step, and the registers are needed)
     constexpr int NIT = ws_nit(Kind<DT>::value, TILE, KS);
     constexpr int P = ws_depth(TILE, KS);
     auto kern = k_conv_ws<DT, t.MB, t.WM, t.WN, t.NB, KS, CPG, D, NIT, P, kWsLoaderWaves>;

@@ -753,7 +753,10 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
   // converted group twice the MFMA work of the 64 x 128 tile) wherever it still fills the chip
   static const std::vector<int> ws_wide3 = tile_order("DSX_TILES_WS_WIDE", {TILE_128x128, TILE_64x128});
   static const std::vector<int> ws_wide1 = tile_order("DSX_TILES_WS_WIDE_1X1", {TILE_128x128, TILE_64x128});
-  const std::vector<int>& ws_wide = ks == 1 ? ws_wide1 : ws_wide3;
+  // 1 x 1 without GroupNorm / Swish in front (residual and attention-output convs): the loaders only copy, the kernel is
+  // bound by the weight stream, and only the one-N-block tiles have the deep weight ring (measured: 32^2 layers -2 us each)
+  static const std::vector<int> ws_wide1raw = tile_order("DSX_TILES_WS_WIDE_1X1_RAW", {TILE_64x128, TILE_128x128});
+  const std::vector<int>& ws_wide = ks == 1 ? ((a.has_gn || a.swish) ? ws_wide1 : ws_wide1raw) : ws_wide3;
   static const std::vector<int> ws_narrow = tile_order("DSX_TILES_WS_NARROW", {TILE_256x64, TILE_128x64, TILE_64x64});
   // Pass -1 (experiment, off: DSX_CPG2=1 enables it): few input channels at a large map (the 64-channel layers of the
   // 128^2 level) on the two-chunk variant of k_conv_mfma: every 64 input channels are one staged group, three
