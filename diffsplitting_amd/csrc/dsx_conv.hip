@@ -1179,6 +1179,20 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   };
   prefetch_epilogue(cur, ntile > 3, n3.b);
 
+  // Until the loaders have staged the first image the compute waves only wait (one DMA round trip plus a conversion).
+  // A residual 1 x 1 conv uses that time for the finalize of the GroupNorm between the two 3 x 3 convs of its block
+  // (its statistics were complete before this launch started): one (image, group) item per compute wave, plus that
+  // GroupNorm's consumer's L2 weight prefetch -- one k_gn_finalize launch less per block.
+  unsigned fin_pf_acc = 0u;
+  if constexpr (KS == 1) {
+    if (a.fin_on) {
+      fin_pf_acc = l2_prefetch(a.fin.pf, blockIdx.x, gridDim.x, tid, 256);
+      const int nitems = a.fin.B * a.fin.groups;
+      for (int item = (int)blockIdx.x * 4 + wave; item < nitems; item += (int)gridDim.x * 4)
+        gn_finalize_item(a.fin, item % a.fin.B, item / a.fin.B, lane);
+    }
+  }
+
   ws_barrier();   // scale/shift visible to the loaders
   ws_barrier();   // image of item 0 is ready
   DSX_STAMP_T(0, tid == 0);
@@ -1206,6 +1220,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #undef DSX_WS_ITEM_NEXT
       });
   }
+  if constexpr (KS == 1) l2_prefetch_retire(a.fin.pf, fin_pf_acc);
 }
 
 

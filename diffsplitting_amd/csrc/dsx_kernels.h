@@ -48,6 +48,78 @@ __device__ __forceinline__ void l2_prefetch_retire(const PrefetchArgs& pf, unsig
 }
 #endif
 
+// GroupNorm of the concatenation of (t0, t1) -> scale/shift[b][C0+C1]
+struct GnFinArgs {
+  const void* part0; int C0, nchunk0, f32_0;   // partials: double (k_chan_stats) or float (conv epilogue)
+  const void* part1; int C1, nchunk1, f32_1;
+  int B, groups;
+  double count;          // elements per channel (H*W)
+  const float* gamma;    // [C0+C1]
+  const float* beta;
+  float eps;
+  float* scale;          // [B][C0+C1]
+  float* shift;
+  PrefetchArgs pf;       // weight slices of the conv this GroupNorm feeds (see l2_prefetch)
+};
+#if defined(__HIPCC__)
+// One (image, group) item of the GroupNorm finalize, by one wave: lanes stride over (channel-in-group, chunk)
+// partials, fixed assignment + fixed butterfly order -> bitwise reproducible.  Used by k_gn_finalize (one wave per
+// workgroup) and by the loader waves of a residual 1 x 1 conv that hosts the finalize of the block's second GroupNorm.
+__device__ __forceinline__ void gn_finalize_item(const GnFinArgs& a, const int b, const int g, const int lane) {
+  const int C = a.C0 + a.C1;
+  const int cpg = C / a.groups;
+  const int c_lo = g * cpg;
+  double s = 0, q = 0;
+  // channels of this group that live in source 0 / source 1; the loads of a lane are independent, so
+  // they are issued 8 at a time (the kernel is pure load latency otherwise)
+  const int n0 = max(0, min(a.C0, c_lo + cpg) - c_lo);      // first n0 channels from source 0
+  const int n1 = cpg - n0;
+  auto accumulate = [&](const void* part, int is_f32, int nsrc, int nchunk, int Csrc, int cbase) __attribute__((always_inline)) {
+    const int items = nsrc * nchunk;
+    for (int i0 = lane; i0 < items; i0 += 64 * 8) {
+      double ps[8], pq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 64;
+        ps[u] = 0; pq[u] = 0;
+        if (i < items) {
+          const int ch = i / nsrc, c = cbase + (i - ch * nsrc);
+          const size_t idx = (((size_t)b * nchunk + ch) * Csrc + c) * 2;
+          if (is_f32) { const float2 v = *(const float2*)((const float*)part + idx); ps[u] = v.x; pq[u] = v.y; }
+          else { const double2 v = *(const double2*)((const double*)part + idx); ps[u] = v.x; pq[u] = v.y; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += ps[u]; q += pq[u]; }
+    }
+  };
+  // gamma / beta of this lane's channel: issued with the partial sums (one memory round trip, not two)
+  const int c_own = c_lo + lane;
+  const bool own = lane < cpg;
+  const float g_own = own ? a.gamma[c_own] : 0.f, b_own = own ? a.beta[c_own] : 0.f;
+  if (n0 > 0) accumulate(a.part0, a.f32_0, n0, a.nchunk0, a.C0, c_lo);
+  if (n1 > 0) accumulate(a.part1, a.f32_1, n1, a.nchunk1, a.C1, c_lo + n0 - a.C0);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  const double n = a.count * cpg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float meanf = (float)mean;
+  if (own) {
+    const float sc = rstd * g_own;
+    a.scale[(size_t)b * C + c_own] = sc;
+    a.shift[(size_t)b * C + c_own] = b_own - meanf * sc;
+  }
+  for (int c = c_lo + lane + 64; c < c_lo + cpg; c += 64) {   // groups wider than a wave (not in the reference configs)
+    const float sc = rstd * a.gamma[c];
+    a.scale[(size_t)b * C + c] = sc;
+    a.shift[(size_t)b * C + c] = a.beta[c] - meanf * sc;
+  }
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // Fused conv:  out = conv_{KSxKS, stride S}( act( gn(x) ) ) + bias + film + resid
 //   x is the channel-concatenation of up to two NHWC fp32 tensors (skip
@@ -100,6 +172,8 @@ struct ConvArgs {
   const float* gn_gamma; const float* gn_beta;
   int gn_groups; float gn_eps;
   PrefetchArgs pf;        // weight slices of the next conv launch (see l2_prefetch)
+  int fin_on;             // k_conv_ws: the loader waves, idle while the last epilogue runs, finalize another GroupNorm
+  GnFinArgs fin;          //   (the one between the two convs behind this residual 1 x 1 conv; fin.pf = its consumer's weights)
   int ksplit;             // split-K slices (1 = none); slice s writes raw sums to out + s*slab_stride
   int groups_per_split;   // channel groups per slice
   long long slab_stride;  // elements between slabs
@@ -156,19 +230,6 @@ hipError_t launch_conv_naive(const NaiveConvArgs& a, hipStream_t st);
 //   part[((b*nchunk + ch)*C + c)*2 + {0,1}]
 hipError_t launch_chan_stats(const void* x, int bf16, int B, int HW, int C, int nchunk, double* part,
                              hipStream_t st);
-// GroupNorm of the concatenation of (t0, t1) -> scale/shift[b][C0+C1]
-struct GnFinArgs {
-  const void* part0; int C0, nchunk0, f32_0;   // partials: double (k_chan_stats) or float (conv epilogue)
-  const void* part1; int C1, nchunk1, f32_1;
-  int B, groups;
-  double count;          // elements per channel (H*W)
-  const float* gamma;    // [C0+C1]
-  const float* beta;
-  float eps;
-  float* scale;          // [B][C0+C1]
-  float* shift;
-  PrefetchArgs pf;       // weight slices of the conv this GroupNorm feeds (see l2_prefetch)
-};
 hipError_t launch_gn_finalize(const GnFinArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------

@@ -108,62 +108,11 @@ hipError_t launch_chan_stats(const void* x, int bf16, int B, int HW, int C, int 
 //   y = (x-mean)*rstd*gamma + beta  ==  x*scale + shift
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
-  // one wave per (image, group): lanes stride over (channel-in-group, chunk) partials,
-  // fixed assignment + fixed butterfly order -> bitwise reproducible
-  const int b = blockIdx.x, g = blockIdx.y;
+  // one wave per (image, group)
   const int lane = threadIdx.x;
   // first, so that they fly together with this launch's own loads: the consumer conv's weight slices -> this XCD's L2
   const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, lane, 64);
-  const int C = a.C0 + a.C1;
-  const int cpg = C / a.groups;
-  const int c_lo = g * cpg;
-  double s = 0, q = 0;
-  // channels of this group that live in source 0 / source 1; the loads of a lane are independent, so
-  // they are issued 8 at a time (the kernel is pure load latency otherwise)
-  const int n0 = max(0, min(a.C0, c_lo + cpg) - c_lo);      // first n0 channels from source 0
-  const int n1 = cpg - n0;
-  auto accumulate = [&](const void* part, int is_f32, int nsrc, int nchunk, int Csrc, int cbase) {
-    const int items = nsrc * nchunk;
-    for (int i0 = lane; i0 < items; i0 += 64 * 8) {
-      double ps[8], pq[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 64;
-        ps[u] = 0; pq[u] = 0;
-        if (i < items) {
-          const int ch = i / nsrc, c = cbase + (i - ch * nsrc);
-          const size_t idx = (((size_t)b * nchunk + ch) * Csrc + c) * 2;
-          if (is_f32) { const float2 v = *(const float2*)((const float*)part + idx); ps[u] = v.x; pq[u] = v.y; }
-          else { const double2 v = *(const double2*)((const double*)part + idx); ps[u] = v.x; pq[u] = v.y; }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { s += ps[u]; q += pq[u]; }
-    }
-  };
-  // gamma / beta of this lane's channel: issued with the partial sums (one memory round trip, not two)
-  const int c_own = c_lo + lane;
-  const bool own = lane < cpg;
-  const float g_own = own ? a.gamma[c_own] : 0.f, b_own = own ? a.beta[c_own] : 0.f;
-  if (n0 > 0) accumulate(a.part0, a.f32_0, n0, a.nchunk0, a.C0, c_lo);
-  if (n1 > 0) accumulate(a.part1, a.f32_1, n1, a.nchunk1, a.C1, c_lo + n0 - a.C0);
-  s = wave_sum(s); q = wave_sum(q);
-  const double n = a.count * cpg;
-  const double mean = s / n;
-  double var = q / n - mean * mean;
-  if (var < 0) var = 0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-  const float meanf = (float)mean;
-  if (own) {
-    const float sc = rstd * g_own;
-    a.scale[(size_t)b * C + c_own] = sc;
-    a.shift[(size_t)b * C + c_own] = b_own - meanf * sc;
-  }
-  for (int c = c_lo + lane + 64; c < c_lo + cpg; c += 64) {   // groups wider than a wave (not in the reference configs)
-    const float sc = rstd * a.gamma[c];
-    a.scale[(size_t)b * C + c] = sc;
-    a.shift[(size_t)b * C + c] = a.beta[c] - meanf * sc;
-  }
+  gn_finalize_item(a, blockIdx.x, blockIdx.y, lane);
   l2_prefetch_retire(a.pf, pf_acc);
 }
 

@@ -626,6 +626,11 @@ struct dsx_exec {
   // tiling are known)
   std::shared_ptr<PrefetchArgs> pending_gn_pf;
   std::shared_ptr<PrefetchArgs> prev_img_pf;
+  // GroupNorm finalize hosted by the residual 1 x 1 conv in front of it (k_conv_ws loader waves): armed by plan_conv for
+  // the conv plan_res marks, consumed by the plan_gn that follows it immediately.  Shapes only: both planner passes agree.
+  struct HostedFin { bool on = false; GnFinArgs a{}; std::shared_ptr<PrefetchArgs> pf; };
+  std::shared_ptr<HostedFin> fin_host;
+  bool fin_host_armed = false;
   unsigned long long* stamp_buf = nullptr;
   std::vector<StatInfo> stats;
   // fixed buffers
@@ -829,6 +834,7 @@ struct ConvSpec {
   const GnW* gn = nullptr;   // GroupNorm over cat(x0, x1) in front of the conv (finalised by k_gn_finalize, or inside
                              // the consumer by k_conv_img)
   bool has_resid = false;
+  bool host_fin = false;     // plan_res: this residual 1 x 1 conv may host the finalize of the block's second GroupNorm
   bool swish = false;
   const float* film = nullptr; int film_bs = 0;
   const void* resid = nullptr; int resid_ld = 0;
@@ -980,6 +986,9 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       reduce_stats = (float*)si.part;
     }
   }
+  static const int host_on = getenv("DSX_HOST_FIN") ? atoi(getenv("DSX_HOST_FIN")) : 1;
+  const bool host_fin = s.host_fin && host_on && use_ws;   // (shapes only: the sizing pass arms it too, plan_gn counts launches)
+  if (host_fin) ex->fin_host_armed = true;
   if (ex->sizing) return DSX_OK;
   if (mfma_ok) {
     const ConvTileInfo ti = conv_tile_info(tile);
@@ -1018,8 +1027,18 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
           const size_t wblock = (size_t)a.kchunks * ks * ks * 2 * 1024;     // bytes of one 32-channel N block's fragments
           *ex->pending_gn_pf = PrefetchArgs{a.wpack, (unsigned)(wblock * (ti.BN / 32)), NT, nullptr};
         }
-        add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
-               [=](hipStream_t st) { return launch_conv_ws(dtype, tile, ks, w, st); });
+        if (host_fin) {
+          auto hf = std::make_shared<dsx_exec::HostedFin>();
+          ex->fin_host = hf;
+          add_op(ex, DSX_OP_CONV_MFMA, d + " ws +gn", flops, bytes, [=](hipStream_t st) {
+            ConvArgs b = w;
+            if (hf->on) { b.fin_on = 1; b.fin = hf->a; if (hf->pf) b.fin.pf = *hf->pf; }
+            return launch_conv_ws(dtype, tile, ks, b, st);
+          });
+        } else {
+          add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
+                 [=](hipStream_t st) { return launch_conv_ws(dtype, tile, ks, w, st); });
+        }
       } else {
         add_op(ex, DSX_OP_CONV_MFMA, a.cpg == 2 ? d + " g2" : d, flops, bytes,
                [=](hipStream_t st) { return launch_conv(dtype, tile, ks, stride, a, st); });
@@ -1064,7 +1083,9 @@ static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* 
   const int C = t0.C + (t1 ? t1->C : 0);
   *scale = (float*)ws_alloc(ex, (size_t)ex->B * C * sizeof(float));
   *shift = (float*)ws_alloc(ex, (size_t)ex->B * C * sizeof(float));
-  ex->launches++;
+  const bool hosted = ex->fin_host_armed;      // the launch in front is a residual 1 x 1 conv whose loader waves do it
+  ex->fin_host_armed = false;
+  if (!hosted) ex->launches++;
   if (ex->sizing) return;
   GnFinArgs a{};
   a.part0 = ex->stats[t0.id].part; a.C0 = t0.C; a.nchunk0 = ex->stats[t0.id].nchunk;
@@ -1077,6 +1098,11 @@ static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* 
   a.scale = *scale; a.shift = *shift;
   auto pf = std::make_shared<PrefetchArgs>(PrefetchArgs{nullptr, 0u, 0, nullptr});
   ex->pending_gn_pf = pf;    // plan_conv fills it in once it has chosen the consumer's kernel and tiling
+  if (hosted && ex->fin_host) {
+    ex->fin_host->a = a; ex->fin_host->pf = pf; ex->fin_host->on = true;
+    ex->fin_host.reset();
+    return;
+  }
   add_op(ex, DSX_OP_GN_FINALIZE, fmt("gn_finalize C=%d", C), 0.0, 0.0,
          [=](hipStream_t st) { GnFinArgs b = a; b.pf = *pf; return launch_gn_finalize(b, st); });
 }
@@ -1097,6 +1123,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
     r = new_tensor(ex, md.cout, H, W);
     ConvSpec cr{};
     cr.w = &md.res; cr.x0 = x0; if (x1) cr.x1 = *x1; cr.out = r;
+    cr.host_fin = true;
     if ((rc = plan_conv(ex, cr))) return rc;
   } else {
     r = x0;
@@ -1106,6 +1133,7 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
   c2.w = &md.conv2; c2.x0 = h; c2.gn = &md.gn2; c2.swish = true;
   c2.resid = r.p; c2.resid_ld = md.cout; c2.has_resid = true; c2.out = o; c2.want_stats = true;
   if ((rc = plan_conv(ex, c2))) return rc;
+  ex->fin_host_armed = false; ex->fin_host.reset();
   if (!md.attn) { y = o; return DSX_OK; }
   // SelfAttention (unet.py:113-142)
   const int C = md.cout, L = H * W, B = ex->B;

@@ -98,8 +98,9 @@ def test_plan_rejects_sources_of_2gib():
 
 
 def test_headline_config_launch_count():
-    """C2 (sr_sr3_16_128, B=16): one UNet forward is 148 launches (94 conv + 46 finalize + 6 attention + 2 split-K
-    reduce; 194 in round 1).  A planner change that adds launches shows up here, without a GPU."""
+    """C2 (sr_sr3_16_128, B=16): one UNet forward is 134 launches (94 conv + 32 finalize + 6 attention + 2 split-K
+    reduce; 194 in round 1): 14 GroupNorm finalizes run inside the residual 1 x 1 conv in front of them.  A planner
+    change that adds launches shows up here, without a GPU."""
     from diffsplitting_amd import engine
     flavour, kw, B, H, W, cc = CONFIGS["c2_sr3_128_b16"]
     cfg = engine.make_cfg(flavour, kw["in_channel"], kw["out_channel"], kw["inner_channel"], kw["norm_groups"],
@@ -107,4 +108,4 @@ def test_headline_config_launch_count():
     for dt in ("f32", "bf16", "f16"):
         a, b, n = engine.plan_dry_run(cfg, dt, B, H, W, cc)
         assert a == b
-        assert n <= 148, (dt, n)
+        assert n <= 134, (dt, n)
