@@ -1140,11 +1140,19 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   float4 addv[NB][4], affv[2];
   constexpr bool PRE_RESID = DSX_PRE_RESID_EXPR;   // else the residual is read in the epilogue
   uint4 residv[PRE_RESID ? MB : 1][NB][NR];      // storage type; all-zero bits are 0.0 in both
+  // (a uniform branch, not `cond ? *ptr : zero4`: hipcc turns that select into a flat load through a pointer select
+  // between the global vector and a private copy of zero4 -- scratch, flat loads, and the addrspacecast that its spill
+  // path later fails on with "Operand has incorrect register class ... $src_private_base")
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      addv[nb][j] = (a.bias && !a.film) ? *(const float4*)(a.bias + nbase + 32 * nb + 4 * j) : zero4;
+    for (int j = 0; j < 4; ++j) addv[nb][j] = zero4;
+  if (a.bias && !a.film) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) addv[nb][j] = *(const float4*)(a.bias + nbase + 32 * nb + 4 * j);
+  }
 #pragma unroll
   for (int mb = 0; mb < (PRE_RESID ? MB : 1); ++mb)
 #pragma unroll
@@ -1183,10 +1191,15 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   // A residual 1 x 1 conv uses that time for the finalize of the GroupNorm between the two 3 x 3 convs of its block
   // (its statistics were complete before this launch started): one (image, group) item per compute wave, plus that
   // GroupNorm's consumer's L2 weight prefetch -- one k_gn_finalize launch less per block.
+  // Every launch also uses the wait to pull the NEXT conv launch's weight slices into the L2s that will read them.
+  // (not in the two-N-block 3 x 3 instantiation: it is at the register limit, and the extra live values cost its main
+  // loop 10 %)
+  constexpr bool PF_OK = !(NB == 2 && KS == 3);
   unsigned fin_pf_acc = 0u;
+  if constexpr (PF_OK) fin_pf_acc = l2_prefetch(a.pf, blockIdx.x, gridDim.x, tid, 256);
   if constexpr (KS == 1) {
     if (a.fin_on) {
-      fin_pf_acc = l2_prefetch(a.fin.pf, blockIdx.x, gridDim.x, tid, 256);
+      fin_pf_acc |= l2_prefetch(a.fin.pf, blockIdx.x, gridDim.x, tid, 256);
       const int nitems = a.fin.B * a.fin.groups;
       for (int item = (int)blockIdx.x * 4 + wave; item < nitems; item += (int)gridDim.x * 4)
         gn_finalize_item(a.fin, item % a.fin.B, item / a.fin.B, lane);
@@ -1220,7 +1233,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #undef DSX_WS_ITEM_NEXT
       });
   }
-  if constexpr (KS == 1) l2_prefetch_retire(a.fin.pf, fin_pf_acc);
+  if constexpr (PF_OK) l2_prefetch_retire(a.pf, fin_pf_acc);   // (both sinks are always null)
 }
 
 

@@ -172,7 +172,7 @@ struct ConvArgs {
   const float* gn_gamma; const float* gn_beta;
   int gn_groups; float gn_eps;
   PrefetchArgs pf;        // weight slices of the next conv launch (see l2_prefetch)
-  int fin_on;             // k_conv_ws: the loader waves, idle while the last epilogue runs, finalize another GroupNorm
+  int fin_on;             // k_conv_ws: the compute waves, idle until the first image is staged, finalize another GroupNorm
   GnFinArgs fin;          //   (the one between the two convs behind this residual 1 x 1 conv; fin.pf = its consumer's weights)
   int ksplit;             // split-K slices (1 = none); slice s writes raw sums to out + s*slab_stride
   int groups_per_split;   // channel groups per slice

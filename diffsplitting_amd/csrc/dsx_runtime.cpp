@@ -626,6 +626,7 @@ struct dsx_exec {
   // tiling are known)
   std::shared_ptr<PrefetchArgs> pending_gn_pf;
   std::shared_ptr<PrefetchArgs> prev_img_pf;
+  std::shared_ptr<PrefetchArgs> prev_ws_pf;    // slot of the previous k_conv_ws launch: the next conv's weight slices
   // GroupNorm finalize hosted by the residual 1 x 1 conv in front of it (k_conv_ws loader waves): armed by plan_conv for
   // the conv plan_res marks, consumed by the plan_gn that follows it immediately.  Shapes only: both planner passes agree.
   struct HostedFin { bool on = false; GnFinArgs a{}; std::shared_ptr<PrefetchArgs> pf; };
@@ -846,6 +847,17 @@ struct ConvSpec {
 static void plan_stats(dsx_exec* ex, const Tensor& t);
 static void plan_gn(dsx_exec* ex, const GnW& g, const Tensor& t0, const Tensor* t1, float** scale, float** shift);
 
+// workgroups per N tile of a k_conv_ws launch (whole XCD groups per N tile, see the kernel)
+static int ws_wg_per_n(const ConvArgs& a) {
+  int wpn = std::min(a.m_tiles, std::max(1, 256 / std::max(1, a.n_tiles)));
+  if (a.n_tiles <= 8 && 8 % a.n_tiles == 0) {
+    const int unit = 8 / a.n_tiles;
+    wpn = std::max(unit, wpn / unit * unit);
+    if (wpn > a.m_tiles) wpn = (a.m_tiles + unit - 1) / unit * unit;
+  }
+  return wpn;
+}
+
 static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   ex->pending_gn_pf.reset();
   ConvArgs a{};
@@ -948,6 +960,9 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
            [=](hipStream_t st) { ConvArgs b = a; b.pf = *pf; return launch_conv_img(dtype, ks, b, st); });
     return DSX_OK;
   }
+  static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
+  static const int ws_enabled = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
+  static const int ws_1x1_enabled = getenv("DSX_WS_1X1") ? atoi(getenv("DSX_WS_1X1")) : 1;
   if (s.gn) {   // every other kernel takes the per-channel scale / shift a k_gn_finalize launch prepares
     float *sc = nullptr, *sh = nullptr;
     plan_gn(ex, *s.gn, s.x0, s.x1.C ? &s.x1 : nullptr, &sc, &sh);
@@ -956,9 +971,6 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   int tile = -1;
   const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
   ex->launches++;
-  static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
-  static const int ws_enabled = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
-  static const int ws_1x1_enabled = getenv("DSX_WS_1X1") ? atoi(getenv("DSX_WS_1X1")) : 1;
   const bool use_ws = mfma_ok && a.cpg != 2 && ws_enabled && (ks != 1 || ws_1x1_enabled) && stride == 1 && a.stage_mode == 0 &&
                       a.ksplit == 1 && conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
   if (fuse_stats && s.want_stats && mfma_ok && (use_ws ? conv_ws_fuses_stats(tile) : conv_tile_fuses_stats(tile)) &&
@@ -1011,33 +1023,34 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
     } else {
       ConvArgs w = a;
       w.xcd_bands = getenv("DSX_XCD_BANDS") ? atoi(getenv("DSX_XCD_BANDS")) : 1;
-      w.ws_wg_per_n = std::min(a.m_tiles, std::max(1, 256 / std::max(1, a.n_tiles)));
-      if (a.n_tiles <= 8 && 8 % a.n_tiles == 0) {   // whole XCD groups per N tile (see k_conv_ws)
-        const int unit = 8 / a.n_tiles;
-        w.ws_wg_per_n = std::max(unit, w.ws_wg_per_n / unit * unit);
-        if (w.ws_wg_per_n > a.m_tiles) w.ws_wg_per_n = (a.m_tiles + unit - 1) / unit * unit;
-      }
+      w.ws_wg_per_n = ws_wg_per_n(a);
       if (use_ws) {
         // this conv's k_gn_finalize launch pulls the weight slices into the L2 of the XCD group that will read them
         // (k_conv_ws keys its N tile on blockIdx % 8 in exactly these two cases)
         static const int pf_on = getenv("DSX_PREFETCH") ? atoi(getenv("DSX_PREFETCH")) : 1;
         const int NT = a.n_tiles;
         const bool keyed = (NT <= 8 && 8 % NT == 0 && w.ws_wg_per_n % (8 / NT) == 0) || (NT % 8) == 0;
-        if (pf_on && ex->pending_gn_pf && keyed) {
-          const size_t wblock = (size_t)a.kchunks * ks * ks * 2 * 1024;     // bytes of one 32-channel N block's fragments
-          *ex->pending_gn_pf = PrefetchArgs{a.wpack, (unsigned)(wblock * (ti.BN / 32)), NT, nullptr};
-        }
+        const size_t wblock = (size_t)a.kchunks * ks * ks * 2 * 1024;     // bytes of one 32-channel N block's fragments
+        const PrefetchArgs mine{a.wpack, (unsigned)(wblock * (ti.BN / 32)), NT, nullptr};
+        static const int pf_ws = getenv("DSX_PREFETCH_WS") ? atoi(getenv("DSX_PREFETCH_WS")) : 1;
+        if (pf_on && ex->pending_gn_pf && keyed) *ex->pending_gn_pf = mine;
+        // no finalize launch in front (1 x 1 without GroupNorm, upsampling conv): the previous k_conv_ws launch carries it
+        else if (pf_on && pf_ws && ex->prev_ws_pf && keyed) *ex->prev_ws_pf = mine;
+        auto npf = std::make_shared<PrefetchArgs>(PrefetchArgs{nullptr, 0u, 0, nullptr});
+        ex->prev_ws_pf = npf;
+        w.pf = PrefetchArgs{nullptr, 0u, 0, nullptr};
         if (host_fin) {
           auto hf = std::make_shared<dsx_exec::HostedFin>();
           ex->fin_host = hf;
           add_op(ex, DSX_OP_CONV_MFMA, d + " ws +gn", flops, bytes, [=](hipStream_t st) {
             ConvArgs b = w;
+            b.pf = *npf;
             if (hf->on) { b.fin_on = 1; b.fin = hf->a; if (hf->pf) b.fin.pf = *hf->pf; }
             return launch_conv_ws(dtype, tile, ks, b, st);
           });
         } else {
           add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
-                 [=](hipStream_t st) { return launch_conv_ws(dtype, tile, ks, w, st); });
+                 [=](hipStream_t st) { ConvArgs b = w; b.pf = *npf; return launch_conv_ws(dtype, tile, ks, b, st); });
         }
       } else {
         add_op(ex, DSX_OP_CONV_MFMA, a.cpg == 2 ? d + " g2" : d, flops, bytes,
@@ -1167,6 +1180,7 @@ static int build_plan(dsx_exec* ex) {
   ex->ops.clear();
   ex->conv_ordinal = 0;
   ex->prev_img_pf.reset();
+  ex->prev_ws_pf.reset();
   ex->pending_gn_pf.reset();
   ex->op_info.clear();
   ex->stats.clear();
