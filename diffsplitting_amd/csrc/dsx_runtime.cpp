@@ -998,7 +998,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       reduce_stats = (float*)si.part;
     }
   }
-  static const int host_on = getenv("DSX_HOST_FIN") ? atoi(getenv("DSX_HOST_FIN")) : 1;
+  const int host_on = getenv("DSX_HOST_FIN") ? atoi(getenv("DSX_HOST_FIN")) : 1;   // (read at every plan: the tests flip it)
   const bool host_fin = s.host_fin && host_on && use_ws;   // (shapes only: the sizing pass arms it too, plan_gn counts launches)
   if (host_fin) ex->fin_host_armed = true;
   if (ex->sizing) return DSX_OK;

@@ -104,6 +104,34 @@ def test_benchmark_batch_matches_single_image_path(dev):
     assert psnr(g["y"][0], y16[0]) > 35.0
 
 
+def test_hosted_groupnorm_finalize_is_bitwise_neutral(dev, monkeypatch):
+    """At the benchmark batch the residual 1 x 1 convs run the finalize of their block's second GroupNorm in their compute
+    waves' start-up wait (one launch less per block).  It is the same per-(image, group) code on the same partial sums
+    as the k_gn_finalize launch it replaces: with DSX_HOST_FIN=0 the forward must be bitwise identical."""
+    name = "sr3_128"
+    sd, _ = golden_state_dict("unet_" + name)
+    case = cases.UNET_CASES[name]
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn((16, 6, 128, 128), generator=gen).to(dev)
+    t = (0.05 + 0.95 * torch.rand((16, 1), generator=gen)).to(dev)
+    for dtype in ("bf16", "f32"):
+        eng = build_engine(case["cfg"], case["flavour"], sd, dtype=dtype)
+        descs = eng.op_descriptions(16, 128, 128)
+        n_host = sum("+gn" in d for d in descs)
+        n_fin = sum(d.startswith("gn_finalize") for d in descs)
+        assert n_host >= 10, (dtype, n_host)
+        y_host = eng.forward(x, t).cpu()
+        monkeypatch.setenv("DSX_HOST_FIN", "0")
+        eng0 = build_engine(case["cfg"], case["flavour"], sd, dtype=dtype)
+        descs0 = eng0.op_descriptions(16, 128, 128)
+        assert sum("+gn" in d for d in descs0) == 0
+        assert sum(d.startswith("gn_finalize") for d in descs0) == n_fin + n_host
+        y_plain = eng0.forward(x, t).cpu()
+        monkeypatch.delenv("DSX_HOST_FIN")
+        assert torch.equal(y_host, y_plain), (dtype, float((y_host - y_plain).abs().max()))
+        print(f"\n{dtype}: {n_host} finalizes hosted by residual convs, {n_fin} launches left; bitwise equal to the unhosted plan")
+
+
 def test_unet_forward_naive_conv_crosscheck(dev, monkeypatch):
     """The plain direct-conv kernel (DSX_CONV_IMPL=naive) and the MFMA kernel agree."""
     monkeypatch.setenv("DSX_CONV_IMPL", "naive")
