@@ -10,7 +10,9 @@ SRCS="dsx_conv.hip dsx_ops.hip dsx_attn.hip"
 if [ "$(cat _obj/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f _obj/*.o; echo "$FLAGS" > _obj/.flags; fi
 pids=()
 for f in $SRCS; do
-  if [ ! -f _obj/$f.o ] || [ $f -nt _obj/$f.o ] || [ dsx_kernels.h -nt _obj/$f.o ]; then
+  newer_inc=0
+  for inc in *.inc; do [ "$inc" -nt _obj/$f.o ] && newer_inc=1; done     # included bodies (dsx_conv_ws_item.inc)
+  if [ ! -f _obj/$f.o ] || [ $f -nt _obj/$f.o ] || [ dsx_kernels.h -nt _obj/$f.o ] || [ $newer_inc = 1 ]; then
     rm -f _obj/$f.o                       # a failed compile must not leave a stale object to link
     hipcc $FLAGS -c $f -o _obj/$f.o &
     pids+=($!)
