@@ -758,6 +758,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x;
+  DSX_STAMP_T(63, tid == 0);                    // kernel entry (diagnostic builds): stamp 0 - stamp 63 = the start-up ramp
   const int lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave8 >= 4;
@@ -787,22 +788,27 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   const int wpn = a.ws_wg_per_n;
   int nt, p0;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, k = bid >> 3, NT = a.n_tiles;
-    if (NT <= 8 && (8 % NT) == 0 && (wpn % (8 / NT)) == 0) {
-      nt = xcd % NT;
+    // (no integer divisions here or below: the host passes quotients and fastdiv magics, see ConvArgs::ws_map)
+    const int bid = blockIdx.x, xcd = bid & 7, k = bid >> 3;
+    if (a.ws_map == 0) {                         // n_tiles in {1, 2, 4, 8} and wpn a multiple of 8 / n_tiles
+      const int lg = a.ws_nt_log2, band = xcd >> lg;
+      nt = xcd & ((1 << lg) - 1);
       // each XCD owns a contiguous band of M tiles (neighbouring tiles share halo rows in its L2) ...
-      if (a.xcd_bands) p0 = (xcd / NT) * (wpn / (8 / NT)) + k;
-      else p0 = k * (8 / NT) + xcd / NT;         // ... or tiles dealt round-robin (DSX_XCD_BANDS=0)
-    } else if ((NT & 7) == 0) {
-      const int per = NT >> 3;
-      nt = xcd + 8 * (k % per);
-      p0 = k / per;
+      if (a.xcd_bands) p0 = band * (wpn >> (3 - lg)) + k;
+      else p0 = (k << (3 - lg)) + band;          // ... or tiles dealt round-robin (DSX_XCD_BANDS=0)
+    } else if (a.ws_map == 1) {                  // n_tiles a multiple of 8
+      const int kq = (int)fastdiv((unsigned)k, a.mg_per);
+      nt = xcd + 8 * (k - kq * a.ws_per);
+      p0 = kq;
     } else {
-      nt = bid / wpn;
+      nt = (int)fastdiv((unsigned)bid, a.mg_wpn);
       p0 = bid - nt * wpn;
     }
   }
-  const int ntile = (a.m_tiles - p0 + wpn - 1) / wpn;
+  // (m_tiles - p0 + wpn - 1) / wpn; one tile per workgroup is the common case
+  const int ntile = wpn >= a.m_tiles ? (p0 < a.m_tiles ? 1 : 0)
+                                     : (a.ws_bigdiv ? (a.m_tiles - p0 + wpn - 1) / wpn
+                                                                : (int)fastdiv((unsigned)(a.m_tiles - p0 + wpn - 1), a.mg_wpn));
   const int total = ntile * G;                  // (tile, group) items, in order
 
   if (loader) {
@@ -816,8 +822,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     // origin offset and four "tile touches the image border" flags change (no divisions, no per-unit
     // bounds arithmetic): zero padding is exactly the border units of border tiles.
     struct TilePos { int tx, ty, b; };
-    const int per_img = a.tiles_x * a.tiles_y;
-    const int adv_x = wpn % a.tiles_x, adv_y = (wpn / a.tiles_x) % a.tiles_y, adv_b = wpn / per_img;
+    const int adv_x = a.ws_adv_x, adv_y = a.ws_adv_y, adv_b = a.ws_adv_b;
     auto tile_advance = [&](TilePos& t) __attribute__((always_inline)) {
       t.tx += adv_x;
       if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; t.ty += 1; }
@@ -843,9 +848,10 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     {
       constexpr int PSTEP = LT >> UPG_LOG2;
       const int pix0 = ltid >> UPG_LOG2;
-      int py = pix0 / PW;
+      static_assert(PSTEP < 65536, "fastdiv range");
+      int py = (int)fastdiv((unsigned)pix0, a.mg_pw);
       int px = pix0 - py * PW;
-      const int dpy = PSTEP / PW, dpx = PSTEP - dpy * PW;
+      const int dpy = a.ws_dpy, dpx = a.ws_dpx;   // PSTEP / PW and the remainder
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const bool have = ltid + it * LT < nunits;
@@ -865,7 +871,13 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         (void*)(a.src1 ? a.src1 : a.src0), 0,
         a.src1 ? (int)min((long long)a.B * a.Hs * a.Ws * a.C1 * ES, 0x7fffffffLL) : 0, 0x00020000);
 
-    TilePos posI{p0 % a.tiles_x, (p0 / a.tiles_x) % a.tiles_y, p0 / per_img};   // tile being issued
+    TilePos posI;                                                                // tile being issued
+    {
+      const int q1 = (int)fastdiv((unsigned)p0, a.mg_tiles_x);                  // p0 / tiles_x
+      posI.b = (int)fastdiv((unsigned)p0, a.mg_per_img);
+      posI.tx = p0 - q1 * a.tiles_x;
+      posI.ty = q1 - posI.b * a.tiles_y;
+    }
     TilePos posC = posI;                                                         // tile being consumed
     int baseI = tile_base(posI), flagsI = tile_flags(posI), flagsC = flagsI;
     int gI = 0;               // group of the next item to issue
@@ -1007,11 +1019,15 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       fetch(slotF);
       if (++slotF == NSLOT) slotF = 0;
     };
+    DSX_STAMP_T(110, tid == 256);       // tables built
     while (issued < NSLOT && issued < total) issue_next();
+    DSX_STAMP_T(111, tid == 256);       // first DMAs issued
     ws_barrier();                       // scale/shift of tiles 0 and 1 are in LDS
     wait_young(min(P, total - 1));
+    DSX_STAMP_T(112, tid == 256);       // item 0 has landed
     fetch_next();                       // item 0
     convert(0);
+    DSX_STAMP_T(113, tid == 256);       // item 0 converted
     if (total > 1) {
       wait_young(min(P - 1, total - 2));
       fetch_next();                     // item 1
@@ -1021,16 +1037,16 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     for (int v = 0; v < total; ++v) {
       // the slot of item v was copied to registers two iterations ago: reuse it for item v+NSLOT
       if (issued < total) issue_next();
-      DSX_STAMP_T(65 + 4 * v, tid == 256 && v < 15);
+      DSX_STAMP_T(65 + 4 * v, tid == 256 && v < 9);
       if (v + 1 < total) convert((v + 1) & 1);
-      DSX_STAMP_T(66 + 4 * v, tid == 256 && v < 15);
+      DSX_STAMP_T(66 + 4 * v, tid == 256 && v < 9);
       if (v + 2 < total) {
         wait_young(min(P - 1, total - 3 - v));
         fetch_next();                   // item v+2
       }
-      DSX_STAMP_T(67 + 4 * v, tid == 256 && v < 15);
+      DSX_STAMP_T(67 + 4 * v, tid == 256 && v < 9);
       ws_barrier();
-      DSX_STAMP_T(68 + 4 * v, tid == 256 && v < 15);
+      DSX_STAMP_T(68 + 4 * v, tid == 256 && v < 9);
     }
     return;
   }
@@ -1085,7 +1101,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   // Tile walk without divisions: (tx, ty, image) of tile p0 + k*wpn, advanced by the decomposed stride.
   struct TilePos { int tx, ty, b; };
   const int per_img = a.tiles_x * a.tiles_y;
-  const int adv_x = wpn % a.tiles_x, adv_y = (wpn / a.tiles_x) % a.tiles_y, adv_b = wpn / per_img;
+  const int adv_x = a.ws_adv_x, adv_y = a.ws_adv_y, adv_b = a.ws_adv_b;
   auto tile_advance = [&](TilePos& t) __attribute__((always_inline)) {
     t.tx += adv_x;
     if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; t.ty += 1; }
@@ -1106,7 +1122,13 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   auto tile_pixel0 = [&](const TilePos& t) __attribute__((always_inline)) -> int {   // first output pixel of tile t (uniform)
     return (t.b * a.Ho + (t.ty << a.th_log2)) * a.Wo + (t.tx << a.tw_log2);
   };
-  TilePos cur{p0 % a.tiles_x, (p0 / a.tiles_x) % a.tiles_y, p0 / per_img};   // tile ti (being multiplied)
+  TilePos cur;             // tile ti (being multiplied)
+  {
+    const int q1 = (int)fastdiv((unsigned)p0, a.mg_tiles_x);
+    cur.b = (int)fastdiv((unsigned)p0, a.mg_per_img);
+    cur.tx = p0 - q1 * a.tiles_x;
+    cur.ty = q1 - cur.b * a.tiles_y;
+  }
   TilePos nxt = cur;       // tile ti + 1
   tile_advance(nxt);
   TilePos nn = nxt;        // tile ti + 2

@@ -27,7 +27,10 @@ struct PrefetchArgs {
   int nslices;
   unsigned* sink;         // always nullptr
 };
+// n / d for n, d < 65536 as a multiply-high: magic = d == 1 ? 0 : floor(2^32 / d) + 1 (exact: n * (magic * d - 2^32) < 2^32)
+inline unsigned fastdiv_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d) + 1u; }
 #if defined(__HIPCC__)
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
 __device__ __forceinline__ unsigned l2_prefetch(const PrefetchArgs& pf, unsigned lin_block, unsigned nblocks_total, int tid, int nthreads) {
   unsigned acc = 0u;
   if (pf.base == nullptr || pf.nslices <= 0) return acc;
@@ -161,6 +164,15 @@ struct ConvArgs {
                           // 64-channel layer is ONE group, no K loop)
   int ws_wg_per_n;        // warp-specialised kernel: persistent workgroups per N tile (0: k_conv_mfma)
   int xcd_bands;          // k_conv_ws: an XCD's workgroups take a contiguous band of M tiles (else round-robin)
+  // k_conv_ws start-up without integer divisions (a dozen of them cost ~2000 cycles before the first DMA could be issued):
+  // the host passes the quotients it can compute and multiply-high magics (fastdiv) for the per-workgroup ones.
+  int ws_map;             // blockIdx -> (N tile, first M tile): 0 N tiles dealt over XCDs (n_tiles in {1,2,4,8}), 1 n_tiles % 8 == 0, 2 plain
+  int ws_nt_log2;         // ws_map 0: log2(n_tiles)
+  int ws_per;             // ws_map 1: n_tiles / 8
+  int ws_adv_x, ws_adv_y, ws_adv_b;   // tile walk stride wpn decomposed: wpn % tiles_x, (wpn / tiles_x) % tiles_y, wpn / (tiles_x * tiles_y)
+  int ws_dpy, ws_dpx;     // loader tables: (loader threads / units per pixel) / PW and the remainder
+  unsigned mg_tiles_x, mg_per_img, mg_pw, mg_wpn, mg_per;   // fastdiv magics (dividends < 65536, see fastdiv)
+  int ws_bigdiv;          // m_tiles + wpn >= 65536: the tiles-per-workgroup quotient needs a real division
   float* stat_part;       // fused GroupNorm partials [B][tiles_x*tiles_y*WM][Cout][2] (fp32) or nullptr
   unsigned long long* stamp;  // diagnostic s_memtime stamps of workgroup `stamp_block` (or nullptr)
   int stamp_block;

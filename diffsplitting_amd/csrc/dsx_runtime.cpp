@@ -1024,6 +1024,21 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       ConvArgs w = a;
       w.xcd_bands = getenv("DSX_XCD_BANDS") ? atoi(getenv("DSX_XCD_BANDS")) : 1;
       w.ws_wg_per_n = ws_wg_per_n(a);
+      {   // division-free start-up of k_conv_ws: quotients and fastdiv magics (see ConvArgs::ws_map)
+        const int NT = a.n_tiles, wpn = w.ws_wg_per_n, per_img = a.tiles_x * a.tiles_y;
+        w.ws_map = (NT <= 8 && 8 % NT == 0 && wpn % (8 / NT) == 0) ? 0 : ((NT % 8) == 0 ? 1 : 2);
+        w.ws_nt_log2 = NT <= 8 ? ilog2(NT) : 0;
+        w.ws_per = NT >> 3;
+        w.ws_adv_x = wpn % a.tiles_x; w.ws_adv_y = (wpn / a.tiles_x) % a.tiles_y; w.ws_adv_b = wpn / per_img;
+        const int PW = ((1 << a.tw_log2) - 1) + ks;                       // stride 1
+        const int upg = 4 * conv_chunk_multiple(ks);                      // 16-byte units per pixel and group
+        const int pstep = 256 / upg;                                      // loader threads / units per pixel
+        w.ws_dpy = pstep / PW; w.ws_dpx = pstep - w.ws_dpy * PW;
+        w.mg_tiles_x = fastdiv_magic((unsigned)a.tiles_x); w.mg_per_img = fastdiv_magic((unsigned)per_img);
+        w.mg_pw = fastdiv_magic((unsigned)PW); w.mg_wpn = fastdiv_magic((unsigned)wpn);
+        w.mg_per = fastdiv_magic((unsigned)std::max(1, w.ws_per));
+        w.ws_bigdiv = ((long long)a.m_tiles + wpn >= 65536 || a.tiles_x >= 65536 || per_img >= 65536) ? 1 : 0;
+      }
       if (use_ws) {
         // this conv's k_gn_finalize launch pulls the weight slices into the L2 of the XCD group that will read them
         // (k_conv_ws keys its N tile on blockIdx % 8 in exactly these two cases)
