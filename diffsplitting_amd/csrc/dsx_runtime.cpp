@@ -1038,6 +1038,21 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         w.mg_pw = fastdiv_magic((unsigned)PW); w.mg_wpn = fastdiv_magic((unsigned)wpn);
         w.mg_per = fastdiv_magic((unsigned)std::max(1, w.ws_per));
         w.ws_bigdiv = ((long long)a.m_tiles + wpn >= 65536 || a.tiles_x >= 65536 || per_img >= 65536) ? 1 : 0;
+        // the magics are exact for dividends below 65536; check the ones this launch can produce (a few thousand
+        // multiplications per conv at plan time) rather than trust the bound
+        auto exact = [](unsigned d, unsigned magic, unsigned nmax) {
+          for (unsigned n = 0; n <= nmax; ++n) {
+            const unsigned q = magic ? (unsigned)(((unsigned long long)n * magic) >> 32) : n;
+            if (q != n / d) return false;
+          }
+          return true;
+        };
+        const unsigned grid = (unsigned)(NT * wpn);
+        const unsigned nt_max = w.ws_bigdiv ? 0u : (unsigned)(a.m_tiles + wpn);
+        if (!exact((unsigned)a.tiles_x, w.mg_tiles_x, grid) || !exact((unsigned)per_img, w.mg_per_img, grid) ||
+            !exact((unsigned)PW, w.mg_pw, 255u) || !exact((unsigned)wpn, w.mg_wpn, std::max(grid, nt_max)) ||
+            !exact((unsigned)std::max(1, w.ws_per), w.mg_per, grid >> 3))
+          return fail(DSX_ERR_INVALID, "planner: fastdiv magic not exact for conv %dx%d @%dx%d", ks, ks, a.Ho, a.Wo);
       }
       if (use_ws) {
         // this conv's k_gn_finalize launch pulls the weight slices into the L2 of the XCD group that will read them
