@@ -63,10 +63,12 @@ def test_unet_forward_bf16_psnr(name, dev):
     assert p > 35.0
 
 
-@pytest.mark.parametrize("name", ["sr3_tiny", "hagen_64", "sr3_128"])
+@pytest.mark.parametrize("name", ["sr3_tiny", "ddpm_tiny", "hagen_64", "sr3_128"])
 def test_unet_forward_persistent_kernel_forced(name, dev, monkeypatch):
     """The warp-specialised persistent conv kernel (the one the B = 16 benchmark runs on) forced onto the
-    small test grids (DSX_WS_MIN_GRID=1): fp32 build within 1e-3 of the golden output, bf16 build by PSNR."""
+    small test grids (DSX_WS_MIN_GRID=1): fp32 build within 1e-3 of the golden output, bf16 build by PSNR.
+    (ddpm_tiny is 32 x 48: three tiles per row, i.e. the multiply-high divisions of the kernel's start-up with a
+    divisor that is not a power of two.)"""
     monkeypatch.setenv("DSX_WS_MIN_GRID", "1")
     sd, g = golden_state_dict("unet_" + name)
     case = cases.UNET_CASES[name]

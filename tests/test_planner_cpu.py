@@ -109,3 +109,60 @@ def test_headline_config_launch_count():
         a, b, n = engine.plan_dry_run(cfg, dt, B, H, W, cc)
         assert a == b
         assert n <= 134, (dt, n)
+
+
+_RANDOM_CHILD = r"""
+import ctypes as C, json, random, sys
+sys.path.insert(0, %r)
+from diffsplitting_amd import _lib
+rng = random.Random(int(sys.argv[1]))
+bad = []
+n_ok = 0
+for case in range(int(sys.argv[2])):
+    levels = rng.choice([2, 3, 4])
+    mults = [1] + sorted(rng.choice([1, 2, 4, 8]) for _ in range(levels - 1))
+    inner = rng.choice([16, 32, 64])
+    groups = rng.choice([8, 16])
+    flavour = rng.choice([0, 1])
+    cond = rng.choice([0, 1, 3]) if flavour == 0 else 0
+    cin = rng.choice([1, 2, 3]) + cond
+    unit = 1 << (levels - 1)
+    # the MFMA tiles are 8 x 8 pixels or larger: bottom-level maps of 8, 16, 24, ... pixels per side (24 and 40 give
+    # three and five tiles per row: tile counts that are not powers of two)
+    H, W = unit * 8 * rng.randint(1, 5), unit * 8 * rng.randint(1, 5)
+    B = rng.choice([1, 2, 3, 5, 8, 16])
+    attn = [rng.choice([H, H // 2 or 1, 16])] if rng.random() < 0.4 else []
+    cfg = _lib.UnetCfg()
+    cfg.flavour = flavour; cfg.in_channel = cin; cfg.out_channel = rng.choice([1, 2, 3]); cfg.inner_channel = inner
+    cfg.norm_groups = groups; cfg.res_blocks = rng.choice([1, 2]); cfg.image_size = H; cfg.with_time_emb = 1
+    cfg.n_mults = len(mults); cfg.n_attn_res = len(attn)
+    for i, m in enumerate(mults): cfg.channel_mults[i] = m
+    for i, m in enumerate(attn): cfg.attn_res[i] = m
+    for code in (0, 1, 2):
+        a, b, n = C.c_size_t(), C.c_size_t(), C.c_int()
+        rc = _lib.lib.dsx_plan_dry_run(C.byref(cfg), code, B, H, W, cond, C.byref(a), C.byref(b), C.byref(n))
+        if rc != 0:
+            msg = _lib.lib.dsx_last_error().decode()
+            # shapes the kernels reject are fine as long as they are rejected with a message, not mis-sized
+            if "fastdiv" in msg or "planner" in msg: bad.append((case, code, B, H, W, msg))
+            continue
+        n_ok += 1
+        if a.value != b.value or a.value == 0: bad.append((case, code, B, H, W, a.value, b.value))
+print(json.dumps({"ok": n_ok, "bad": bad}))
+"""
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_shapes_size_and_plan_alike(seed):
+    """Random UNet topologies, batch sizes and (ragged) image sizes, all three operand types, default knobs and the
+    persistent kernel forced onto every grid: the sizing pass and the planning pass of dsx_exec_create's planner walk
+    the same bytes, and the plan-time check of the start-up division magics never trips."""
+    for env in ({}, {"DSX_WS_MIN_GRID": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _RANDOM_CHILD % ROOT, str(seed), "40"], env=e, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        assert not res["bad"], res["bad"][:5]
+        assert res["ok"] >= 90, res
