@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       fin_pf_acc |= l2_prefetch(a.fin.pf, blockIdx.x, gridDim.x, tid, 256);
       const int nitems = a.fin.B * a.fin.groups;
       for (int item = (int)blockIdx.x * 4 + wave; item < nitems; item += (int)gridDim.x * 4)
-        gn_finalize_item(a.fin, item % a.fin.B, item / a.fin.B, lane);
+        gn_finalize_item<1>(a.fin, item % a.fin.B, item / a.fin.B, lane, nullptr);
     }
   }
 

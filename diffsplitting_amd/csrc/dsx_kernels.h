@@ -65,10 +65,14 @@ struct GnFinArgs {
   PrefetchArgs pf;       // weight slices of the conv this GroupNorm feeds (see l2_prefetch)
 };
 #if defined(__HIPCC__)
-// One (image, group) item of the GroupNorm finalize, by one wave: lanes stride over (channel-in-group, chunk)
-// partials, fixed assignment + fixed butterfly order -> bitwise reproducible.  Used by k_gn_finalize (one wave per
+// One (image, group) item of the GroupNorm finalize, by one wave (or NW waves): threads stride over (channel-in-group,
+// chunk) partials, fixed assignment + fixed butterfly order -> bitwise reproducible.  Used by k_gn_finalize (one wave per
 // workgroup) and by the loader waves of a residual 1 x 1 conv that hosts the finalize of the block's second GroupNorm.
-__device__ __forceinline__ void gn_finalize_item(const GnFinArgs& a, const int b, const int g, const int lane) {
+// NW waves share the item (k_gn_finalize_wide: NW = 4 for the 128^2 / 64^2 maps with hundreds of partial rows); their
+// wave sums meet in LDS (`red`, 2 * NW doubles) and are added in wave order.
+template <int NW>
+__device__ __forceinline__ void gn_finalize_item(const GnFinArgs& a, const int b, const int g, const int tid, double* red) {
+  constexpr int NT = 64 * NW;
   const int C = a.C0 + a.C1;
   const int cpg = C / a.groups;
   const int c_lo = g * cpg;
@@ -79,11 +83,11 @@ __device__ __forceinline__ void gn_finalize_item(const GnFinArgs& a, const int b
   const int n1 = cpg - n0;
   auto accumulate = [&](const void* part, int is_f32, int nsrc, int nchunk, int Csrc, int cbase) __attribute__((always_inline)) {
     const int items = nsrc * nchunk;
-    for (int i0 = lane; i0 < items; i0 += 64 * 8) {
+    for (int i0 = tid; i0 < items; i0 += NT * 8) {
       double ps[8], pq[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 64;
+        const int i = i0 + u * NT;
         ps[u] = 0; pq[u] = 0;
         if (i < items) {
           const int ch = i / nsrc, c = cbase + (i - ch * nsrc);
@@ -96,14 +100,21 @@ __device__ __forceinline__ void gn_finalize_item(const GnFinArgs& a, const int b
       for (int u = 0; u < 8; ++u) { s += ps[u]; q += pq[u]; }
     }
   };
-  // gamma / beta of this lane's channel: issued with the partial sums (one memory round trip, not two)
-  const int c_own = c_lo + lane;
-  const bool own = lane < cpg;
+  // gamma / beta of this thread's channel: issued with the partial sums (one memory round trip, not two)
+  const int c_own = c_lo + tid;
+  const bool own = tid < cpg;
   const float g_own = own ? a.gamma[c_own] : 0.f, b_own = own ? a.beta[c_own] : 0.f;
   if (n0 > 0) accumulate(a.part0, a.f32_0, n0, a.nchunk0, a.C0, c_lo);
   if (n1 > 0) accumulate(a.part1, a.f32_1, n1, a.nchunk1, a.C1, c_lo + n0 - a.C0);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if constexpr (NW > 1) {
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = s; red[2 * (tid >> 6) + 1] = q; }
+    __syncthreads();
+    s = 0; q = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { s += red[2 * w]; q += red[2 * w + 1]; }
+  }
   const double n = a.count * cpg;
   const double mean = s / n;
   double var = q / n - mean * mean;
@@ -115,7 +126,7 @@ __device__ __forceinline__ void gn_finalize_item(const GnFinArgs& a, const int b
     a.scale[(size_t)b * C + c_own] = sc;
     a.shift[(size_t)b * C + c_own] = b_own - meanf * sc;
   }
-  for (int c = c_lo + lane + 64; c < c_lo + cpg; c += 64) {   // groups wider than a wave (not in the reference configs)
+  for (int c = c_lo + tid + NT; c < c_lo + cpg; c += NT) {   // groups wider than the workgroup (not in the reference configs)
     const float sc = rstd * a.gamma[c];
     a.scale[(size_t)b * C + c] = sc;
     a.shift[(size_t)b * C + c] = a.beta[c] - meanf * sc;

@@ -3,6 +3,7 @@
 // the sampler update with Philox noise, layout conversion, tile gather / stitch.
 // (Attention: dsx_attn.hip.)
 #include "dsx_kernels.h"
+#include <algorithm>
 
 namespace dsx {
 
@@ -112,12 +113,26 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
   const int lane = threadIdx.x;
   // first, so that they fly together with this launch's own loads: the consumer conv's weight slices -> this XCD's L2
   const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, lane, 64);
-  gn_finalize_item(a, blockIdx.x, blockIdx.y, lane);
+  gn_finalize_item<1>(a, blockIdx.x, blockIdx.y, lane, nullptr);
+  l2_prefetch_retire(a.pf, pf_acc);
+}
+// four waves per (image, group): the launches with hundreds of partial rows per group (128^2 and 64^2 maps) were five
+// dependent load round trips long with one wave
+__global__ __launch_bounds__(256) void k_gn_finalize_wide(const GnFinArgs a) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, 256);
+  gn_finalize_item<4>(a, blockIdx.x, blockIdx.y, tid, red);
   l2_prefetch_retire(a.pf, pf_acc);
 }
 
 hipError_t launch_gn_finalize(const GnFinArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)a.B, (unsigned)a.groups), dim3(64), 0, st, a);
+  const int cpg = (a.C0 + a.C1) / a.groups;
+  const long long items = (long long)cpg * std::max(a.nchunk0, a.nchunk1);   // partial rows x channels per group (upper bound)
+  if (items > 512)
+    hipLaunchKernelGGL(k_gn_finalize_wide, dim3((unsigned)a.B, (unsigned)a.groups), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_gn_finalize, dim3((unsigned)a.B, (unsigned)a.groups), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 
