@@ -28,6 +28,19 @@ UNET_CASES = {
                               channel_mults=(1, 2, 4, 8), attn_res=(), res_blocks=1, image_size=32)),
 }
 
+# BASELINE C1: config/splitting_cifar10_indi.json:43-44,45-62,71 -- UNet 6 -> 6, inner 16, mults [1,2,4,8], GN16, rb 1,
+# no attn_res; InDI replicates the 1-channel x_in out_channel = 6 times (indi.py:80); batch 4 at 32^2, n = 20 (the file)
+# and n = 100 (BASELINE.json); both step counts trip the reference's drift assert: generated under -O
+C1_CASE = dict(flavour="ddpm", B=4, H=32, W=32,
+               cfg=dict(in_channel=6, out_channel=6, inner_channel=16, norm_groups=16,
+                        channel_mults=(1, 2, 4, 8), attn_res=(), res_blocks=1, image_size=32))
+C1_STEPS = (20, 100)
+
+
+def c1_keep(nblocks):
+    """Blocks (of 4 images) of the continuous C1 return that the fixture keeps."""
+    return [0, 1, nblocks // 2, nblocks - 1]
+
 # Full-size cases at the shapes BASELINE.json names (C3 / C4 / C5): fixtures hold digests of the reference's
 # outputs (crops, strided grids, per-channel sums), the GPU tests compare whole tensors with the oracle.
 _HAGEN = dict(inner_channel=16, norm_groups=16, channel_mults=(1, 2, 4, 8), attn_res=(), res_blocks=1, image_size=32)
@@ -98,6 +111,7 @@ _COND_SHAPES = {
     "indi_loop": (3, 1, 32, 48),
     "joint_loop": (2, 1, 32, 32),
     "time_pred": (3, 1, 32, 32),
+    "c1_cifar": (4, 1, 32, 32),
 }
 
 

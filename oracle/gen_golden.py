@@ -122,6 +122,23 @@ for n, t0 in ((1, 1.0), (3, 1.0), (10, 1.0), (20, 1.0), (4, 0.6)):
     last = indi.inference(x_in, continuous=False, t_float_start=t0)
     save(f"loop_indi_n{n}_t{t0}", keys=jstr(ks), ret=ret.numpy(), last=last.numpy())
 
+# BASELINE C1 (config/splitting_cifar10_indi.json): UNet 6 -> 6, x_in (4, 1, 32, 32) replicated x6, n = 20 / 100
+case = cases.C1_CASE
+for n in cases.C1_STEPS:
+    net, ks = build_unet(case)
+    indi = InDI(net, 32, channels=6, out_channel=6, conditional=False, val_schedule_opt={"n_timestep": n}).eval()
+    indi.set_new_noise_schedule({"n_timestep": n}, "cpu")
+    x_in = cases.make_cond("c1_cifar")
+    torch.manual_seed(cases.LOOP_SEED)
+    ret = indi.inference(x_in, continuous=True, t_float_start=1.0)
+    torch.manual_seed(cases.LOOP_SEED)
+    last = indi.inference(x_in, continuous=False, t_float_start=1.0)
+    # ret stacks (1 + snapshots) batches of 4: the fixture keeps the noisy input, the first snapshot, a middle one and
+    # the final state (cases.C1_KEEP blocks of 4 images) plus the non-continuous return
+    blocks = ret.numpy().reshape(-1, 4, 6, 32, 32)
+    keep = cases.c1_keep(blocks.shape[0])
+    save(f"loop_c1_cifar_n{n}", keys=jstr(ks), nblocks=np.int64(blocks.shape[0]), blocks=blocks[keep], last=last.numpy())
+
 # InDI t sequence + coefficient pin with a stub denoiser
 tseq = {}
 for n, t0 in cases.INDI_T_CASES:

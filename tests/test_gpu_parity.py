@@ -256,6 +256,31 @@ def test_indi_loop(n, t0, dev):
     assert maxabs(x.cpu()[-1:].numpy(), g["last"]) <= FP32_TOL
 
 
+@pytest.mark.parametrize("n", cases.C1_STEPS)
+def test_c1_cifar_indi_loop(n, dev):
+    """BASELINE C1 (config/splitting_cifar10_indi.json:43-44,65,71; indi.py:71-95): UNet 6 -> 6, inner 16, mults
+    [1,2,4,8], GN16, x_in (4, 1, 32, 32) replicated x6, n = 20 and n = 100 (no drift assert in the engine), against the
+    reference-generated fixture and the oracle on the same draws."""
+    sd, g = golden_state_dict(f"loop_c1_cifar_n{n}")
+    cfg = cases.C1_CASE["cfg"]
+    x_in = cases.make_cond("c1_cifar")
+    torch.manual_seed(cases.LOOP_SEED)
+    draws = [torch.randn(4, 6, 32, 32) for _ in range(n + 1)]
+    eng = build_engine(cfg, "ddpm", sd)
+    x0, x, sn = _indi_engine_run(eng, x_in, n, 1.0, 6, draws, dev)
+    torch.cuda.synchronize()
+    blocks = torch.stack([x0] + [s for s in sn.cpu()], dim=0).numpy()
+    assert blocks.shape[0] == int(g["nblocks"])
+    err = maxabs(blocks[cases.c1_keep(blocks.shape[0])], g["blocks"])
+    print(f"C1 cifar InDI n={n}: max|hip - reference| = {err:.3e}")
+    assert err <= FP32_TOL, err
+    assert maxabs(x.cpu()[-1:].numpy(), g["last"]) <= FP32_TOL
+    rec = iter(draws)
+    osd = {"denoise_fn." + k: v for k, v in sd.items()}
+    _, ref = samplers.indi_inference(osd, cfg, x_in, n, 6, randn=lambda shape: next(rec), return_full=True)
+    assert maxabs(x.cpu(), ref) <= FP32_TOL
+
+
 def test_joint_indi_two_streams(dev):
     """JointIndi (joint_indi.py:131-135): the two InDI loops run concurrently on two HIP streams."""
     sd, g = golden_state_dict("loop_joint_n3")

@@ -75,6 +75,24 @@ def test_indi_loop(n, t0):
     np.testing.assert_allclose(last.numpy(), g["last"], rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("n", cases.C1_STEPS)
+def test_c1_cifar_indi_loop(n):
+    """BASELINE C1 (config/splitting_cifar10_indi.json:43-44,65,71): UNet 6 -> 6, 1-channel x_in replicated x6
+    (indi.py:80), batch 4 at 32^2, n = 20 and n = 100 -- both trip the reference's drift assert (generated under -O)."""
+    sd, g = golden_state_dict(f"loop_c1_cifar_n{n}")
+    sd = {"denoise_fn." + k: v for k, v in sd.items()}
+    x_in = cases.make_cond("c1_cifar")
+    torch.manual_seed(cases.LOOP_SEED)
+    ret = samplers.indi_inference(sd, cases.C1_CASE["cfg"], x_in, n, 6, continuous=True, t_float_start=1.0)
+    blocks = ret.numpy().reshape(-1, 4, 6, 32, 32)
+    assert blocks.shape[0] == int(g["nblocks"])
+    np.testing.assert_allclose(blocks[cases.c1_keep(blocks.shape[0])], g["blocks"], rtol=0, atol=5e-5)
+    torch.manual_seed(cases.LOOP_SEED)
+    last = samplers.indi_inference(sd, cases.C1_CASE["cfg"], x_in, n, 6, continuous=False, t_float_start=1.0)
+    assert last.shape == g["last"].shape == (1, 6, 32, 32)
+    np.testing.assert_allclose(last.numpy(), g["last"], rtol=0, atol=5e-5)
+
+
 def test_indi_frame_count_invariant():
     """tests/test_joint_indi.py:9-25 — n_timestep+1 frames for n in {1,2,10} (with the
     working entry point)."""
