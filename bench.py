@@ -77,6 +77,51 @@ def cpu_baseline(sd, batch=4, warm=2, timed=40):
                       f"batch {batch}, {step:.3f} s/step, extrapolated x{SAMPLE_STEPS}"}
 
 
+def kernel_source_sha():
+    """SHA-256 over the kernel and runtime sources the library is built from: what a counters file must name to be
+    quoted next to a measurement of this build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "diffsplitting_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
+def fp32_parity_line(sd, B, steps=20):
+    """The parity build (fp32 MFMA operands, fp32 activations: the <= 1e-3 path) on the same workload: `steps` graph
+    steps at batch B after 3 warm-up steps; the conv family's share is not separated here."""
+    from diffsplitting_amd import engine
+    cfg = engine.make_cfg("sr3", **{k: UNET[k] for k in ("in_channel", "out_channel", "inner_channel", "norm_groups",
+                                                         "channel_mults", "attn_res", "res_blocks", "image_size")})
+    eng = engine.UNetEngine(cfg, "sr3")
+    eng.load_state_dict(sd)
+    eng.finalize("f32")
+    bufs, gam = engine.gaussian_buffers(SCHEDULE)
+    full = engine.gaussian_step_table(bufs, gam, "sr3", clip_denoised=True)
+
+    def sub(n):
+        idx = np.arange(n) % SAMPLE_STEPS
+        return engine.StepTableHost(full.tcond[idx], c1=full.c1[idx], c2=full.c2[idx], sigma=full.sigma[idx],
+                                    a=full.a[idx], b=full.b[idx], predict_eps=True, clip=True)
+    g = torch.Generator().manual_seed(5)
+    cond = torch.randn((B, 3, 128, 128), generator=g).cuda()
+    x = engine.randn((B, 3, 128, 128), seed=77)
+    eng.sample_loop(sub(3), x, cond=cond, seed=1, use_graph=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.sample_loop(sub(steps), x, cond=cond, seed=2, use_graph=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    tf = eng.flops(128, 128) * B / (ms * 1e-3) / 1e12
+    del eng
+    return {"dtype": "f32", "batch_per_gpu": B, "steps": steps, "ms_per_step": ms, "sustained_tflops": tf,
+            "peak": PEAK_TFLOPS["f32"], "frac": tf / PEAK_TFLOPS["f32"],
+            "note": "whole step (UNet forward + update) of the fp32 parity build, v_mfma_f32_32x32x2_f32; peak = dense fp32 MFMA"}
+
+
 def names_of(k):
     return {0: "conv_mfma", 1: "conv_naive", 2: "gn_stats", 3: "gn_finalize", 4: "attn_gemm", 5: "softmax",
             6: "splitk_reduce"}[k]
@@ -132,14 +177,23 @@ def roofline(eng, ex, dtype, iters=3):
     peak = PEAK_TFLOPS[dtype]
     # HBM bytes per conv launch and MFMA-busy fraction come from rocprofv3 PMC passes of this same command
     # (tools/measure_r02.sh -> profiles/r02_counters.json): counters cannot be read live from inside the process
-    traffic, mfma_busy = None, None
-    cpath = os.path.join(ROOT, "profiles", "r02_counters.json")
+    # (tools/measure_r03.sh -> profiles/r03_counters.json, which records the SHA-256 of the kernel sources it was
+    # taken on): counters cannot be read live from inside the process.  Quoted only when that hash is this build's;
+    # otherwise null, and `counters_from` says why.
+    traffic, mfma_busy, counters_from = None, None, None
+    cpath = os.path.join(ROOT, "profiles", "r03_counters.json")
     if os.path.exists(cpath) and dtype == "bf16":
         try:
             cj = json.load(open(cpath))
-            traffic, mfma_busy = cj.get("hbm_bytes_per_conv_launch"), cj.get("mfma_busy_frac_conv")
+            here = kernel_source_sha()
+            if cj.get("kernel_source_sha") == here:
+                traffic, mfma_busy = cj.get("hbm_bytes_per_conv_launch"), cj.get("mfma_busy_frac_conv")
+                counters_from = f"profiles/r03_counters.json @ kernel sources {here[:12]} (rocprofv3 --pmc passes of this command)"
+            else:
+                counters_from = (f"none: profiles/r03_counters.json was taken on kernel sources "
+                                 f"{str(cj.get('kernel_source_sha'))[:12]}, this build is {here[:12]}")
         except Exception:
-            traffic, mfma_busy = None, None
+            traffic, mfma_busy, counters_from = None, None, "none: profiles/r03_counters.json unreadable"
     by_kind = {}
     for r in rows:
         by_kind[r[0]] = by_kind.get(r[0], 0.0) + r[4]
@@ -158,7 +212,7 @@ def roofline(eng, ex, dtype, iters=3):
         print(f"[bench]   {r[4]:8.4f} ms  {tf:8.1f} TF/s  {r[1]}", file=sys.stderr)
     return {"bound": "mfma", "kernel": "k_conv_ws / k_conv_mfma / k_conv_img / k_conv_first (fused GN+Swish+conv implicit GEMM on MFMA; all conv launches of one UNet forward)",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "mfma_busy": mfma_busy,
+            "mfma_busy": mfma_busy, "counters_from": counters_from,
             "launches": len(conv), "avg_launch_ms": conv_ms / max(1, len(conv)),
             "conv_ms_per_step": conv_ms, "conv_ms_per_step_replayed_alone": conv_ms_alone,
             "forward_ms_graph": float(gall.value), "conv_ms_per_step_eager_events": conv_ms_eager,
@@ -204,6 +258,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32-parity", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--split", type=int, default=int(os.environ.get("DSX_BENCH_SPLIT", "1")),
                     help="run the per-GPU batch as this many independent sub-batches on separate HIP streams")
@@ -319,8 +374,12 @@ def main():
         line["sustained_tflops_per_gpu"] = gf * B / (ms_per_step * 1e-3) / 1e12
         if not args.no_roofline:
             line["roofline"] = roofline(eng, eng.executor(B // nsplit, 128, 128, 3), args.dtype)
+        if world == 1 and not args.no_fp32_parity and args.dtype == "bf16":
+            line["fp32_parity"] = fp32_parity_line(sd, B)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd)
+            line["cpu_baseline"] = cpu_baseline(sd)                       # batch 4: the reference's CPU-runnable case
+            b16 = cpu_baseline(sd, batch=16, warm=1, timed=8)             # the headline batch as well
+            line["cpu_baseline"]["batch16"] = {"value": b16["value"], "unit": b16["unit"], "sample": b16["sample"]}
             line["speedup_vs_cpu_baseline"] = images_per_s / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if dist:

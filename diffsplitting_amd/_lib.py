@@ -77,6 +77,15 @@ SIGNATURES = {
     "dsx_stitch": (_i, [_vp, _i64, _i, _i, _i, _pi32, _vp, _pi64, _vp]),
     "dsx_stitch_psnr_blocks": (_i, [_i, _i]),
     "dsx_stitch_psnr": (_i, [_vp, _i64, _i, _i, _i, _pi32, _vp, _pi64, _vp, _vp, _vp]),
+    "dsx_tileplan_create": (_i, [_pi64, _pi64, _pi64, _i, C.POINTER(_vp)]),
+    "dsx_tileplan_destroy": (None, [_vp]),
+    "dsx_tileplan_total": (_i64, [_vp]),
+    "dsx_tileplan_gather": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "dsx_tileplan_gather_norm": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _f, _f, C.POINTER(C.c_double), _i, _vp, _vp, _vp]),
+    "dsx_tileplan_stitch": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "dsx_tileplan_pack_layout": (_i, [_vp, _i, _pi64, _pi64]),
+    "dsx_tileplan_pack": (_i, [_vp, _vp, _i, _i, _i64, _i64, _vp, _vp]),
+    "dsx_tileplan_paste_packed": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
 }
 
 if not os.path.exists(LIB_PATH):

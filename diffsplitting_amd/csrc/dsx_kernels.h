@@ -334,21 +334,30 @@ hipError_t launch_advance(int* step_ctr, hipStream_t st);
 hipError_t launch_randn(float* out, long long n, unsigned long long seed, unsigned long long subseq,
                         hipStream_t st);
 
-hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw,
-                               const int* starts /*dev [count][3]*/, long long count, float* tiles,
-                               hipStream_t st);
+// the tiles of one launch: ids first, first + stride, ... (count of them); the tables a kernel indexes with an id
+// (`starts` [..][3], `regions` [..][8], `off` [..]) live on the device -- the plan's own (dsx_tileplan), or a per-call
+// table with first = 0, stride = 1
+struct TileSeq { long long first, stride, count; };
+hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw, const int* starts /*dev*/, TileSeq seq,
+                               float* tiles, hipStream_t st);
 // crop + dataset normalisation fused (SplitDataset.__getitem__): norm = {mean_inp, std_inp, mean_t0, std_t0, mean_t1, std_t1}
 hipError_t launch_tiles_gather_norm(const float* f0, const float* f1, int H, int W, int ph, int pw, const int* starts,
-                                    long long count, float w0, float w1, const double norm[6], int from_norm_target,
+                                    TileSeq seq, float w0, float w1, const double norm[6], int from_norm_target,
                                     float* tin, float* ttar, hipStream_t st);
-hipError_t launch_stitch(const float* tiles, long long count, int C, int ph, int pw,
-                         const int* regions /*dev [count][8]*/, float* canvas, int H, int W,
-                         hipStream_t st);
-
-// stitch + per-(tile, workgroup, channel) partial sums for RangeInvariantPsnr: part[count][gx][C][8] doubles
-// {sum p, sum p^2, sum g, sum g^2, sum g p, min g, max g, 0}
-hipError_t launch_stitch_psnr(const float* tiles, long long count, int C, int ph, int pw, const int* regions,
-                              float* canvas, const float* gt, int H, int W, double* part, int gx, hipStream_t st);
+// source of a paste: whole predicted tiles (count, C, ph, pw) of the sequence, or the gathered packed exchange buffer
+// [world][rank_stride] (valid regions [C][h][w] of rank q's tiles q, q + world, ... back to back; `off` = pixel offset
+// of each tile id inside its rank's run)
+struct StitchSrc {
+  const float* base; int packed; int ph, pw;
+  const long long* off; long long rank_stride; int world;
+};
+// paste (gt == nullptr) or paste + per-(tile, workgroup, channel) partial sums for RangeInvariantPsnr:
+// part[count][gx][C][8] doubles {sum p, sum p^2, sum g, sum g^2, sum g p, min g, max g, 0}
+hipError_t launch_stitch(const StitchSrc& s, int C, const int* regions /*dev*/, TileSeq seq, float* canvas, int H, int W,
+                         const float* gt, double* part, int gx, hipStream_t st);
+// valid regions of the sequence's tiles -> this rank's flat run (the crop of tile_stitcher.py:38-56 before the collective)
+hipError_t launch_tiles_pack(const float* tiles, int C, int ph, int pw, const int* regions, const long long* off,
+                             TileSeq seq, float* flat, hipStream_t st);
 
 // relu(u) * sigmoid-mask reduction of the TimePredictor head
 hipError_t launch_masked_mean(const float* u, const float* mask, int B, long long n, float* out,

@@ -428,24 +428,26 @@ hipError_t launch_advance(int* step_ctr, hipStream_t st) {
 
 // ---------------------------------------------------------------------------
 // tiles: gather (N,H,W) frames -> (count, ph, pw); stitch valid regions of
-// (count, C, ph, pw) predictions into the (N,H,W,C) canvas (tile_stitcher.py:26-80)
+// (count, C, ph, pw) predictions into the (N,H,W,C) canvas (tile_stitcher.py:26-80).
+// The tiles of a launch are the arithmetic sequence  id = first + k * stride  (k = blockIdx.y): a rank's
+// shard of a plan (or a batch of it) indexes the plan's device tables directly, nothing is uploaded per call.
 // ---------------------------------------------------------------------------
 __global__ void k_tiles_gather(const float* __restrict__ frames, int H, int W, int ph, int pw,
-                               const int* __restrict__ starts, float* __restrict__ tiles) {
-  const long long t = blockIdx.y;
+                               const int* __restrict__ starts, TileSeq seq, float* __restrict__ tiles) {
+  const long long k = blockIdx.y, t = seq.first + k * seq.stride;
   const int n = starts[t * 3], y0 = starts[t * 3 + 1], x0 = starts[t * 3 + 2];
   const int total = ph * pw;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int y = i / pw, x = i % pw;
-    tiles[t * total + i] = frames[((size_t)n * H + (y0 + y)) * W + (x0 + x)];
+    tiles[k * total + i] = frames[((size_t)n * H + (y0 + y)) * W + (x0 + x)];
   }
 }
-hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw, const int* starts,
-                               long long count, float* tiles, hipStream_t st) {
+hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw, const int* starts, TileSeq seq,
+                               float* tiles, hipStream_t st) {
   int gx = (ph * pw + 255) / 256;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(k_tiles_gather, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, st, frames, H, W,
-                     ph, pw, starts, tiles);
+  hipLaunchKernelGGL(k_tiles_gather, dim3((unsigned)gx, (unsigned)seq.count), dim3(256), 0, st, frames, H, W,
+                     ph, pw, starts, seq, tiles);
   return hipGetLastError();
 }
 
@@ -457,7 +459,8 @@ hipError_t launch_tiles_gather(const float* frames, int H, int W, int ph, int pw
 struct GatherNormArgs {
   const float* f0; const float* f1;
   int H, W, ph, pw;
-  const int* starts;       // dev [count][3]
+  const int* starts;       // dev [..][3], indexed by tile id
+  TileSeq seq;
   float w0, w1;
   double mean_inp, std_inp, mt0, st0, mt1, st1;
   int from_norm_target;
@@ -465,7 +468,7 @@ struct GatherNormArgs {
   float* ttar;             // (count, 2, ph, pw)
 };
 __global__ void k_tiles_gather_norm(const GatherNormArgs a) {
-  const long long t = blockIdx.y;
+  const long long k = blockIdx.y, t = a.seq.first + k * a.seq.stride;
   const int n = a.starts[t * 3], y0 = a.starts[t * 3 + 1], x0 = a.starts[t * 3 + 2];
   const int total = a.ph * a.pw;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -476,43 +479,82 @@ __global__ void k_tiles_gather_norm(const GatherNormArgs a) {
     float in;
     if (a.from_norm_target) in = __fadd_rn(__fmul_rn(a.w0, t0), __fmul_rn(a.w1, t1));
     else in = (float)(((double)__fadd_rn(__fmul_rn(a.w0, p0), __fmul_rn(a.w1, p1)) - a.mean_inp) / a.std_inp);
-    a.tin[t * total + i] = in;
-    a.ttar[(t * 2) * total + i] = t0;
-    a.ttar[(t * 2 + 1) * total + i] = t1;
+    a.tin[k * total + i] = in;
+    a.ttar[(k * 2) * total + i] = t0;
+    a.ttar[(k * 2 + 1) * total + i] = t1;
   }
 }
 hipError_t launch_tiles_gather_norm(const float* f0, const float* f1, int H, int W, int ph, int pw, const int* starts,
-                                    long long count, float w0, float w1, const double norm[6], int from_norm_target,
+                                    TileSeq seq, float w0, float w1, const double norm[6], int from_norm_target,
                                     float* tin, float* ttar, hipStream_t st) {
-  GatherNormArgs a{f0, f1, H, W, ph, pw, starts, w0, w1, norm[0], norm[1], norm[2], norm[3], norm[4], norm[5],
+  GatherNormArgs a{f0, f1, H, W, ph, pw, starts, seq, w0, w1, norm[0], norm[1], norm[2], norm[3], norm[4], norm[5],
                    from_norm_target, tin, ttar};
   int gx = (ph * pw + 255) / 256;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(k_tiles_gather_norm, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_tiles_gather_norm, dim3((unsigned)gx, (unsigned)seq.count), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
-__global__ void k_stitch(const float* __restrict__ tiles, int C, int ph, int pw,
-                         const int* __restrict__ regions, float* __restrict__ canvas, int H, int W) {
-  const long long t = blockIdx.y;
+// Where the pixels of tile `t` (the k-th of the launch) come from: whole predicted tiles (count, C, ph, pw), or the
+// packed exchange buffer of tiled multi-GPU prediction -- per rank one flat run of valid regions [C][h][w], tile after
+// tile in id order (rank q owns the ids q, q + world, ...); `off` = pixel offset of every tile inside its rank's run.
+struct TileSrc {
+  const float* base;       // tiles, or the gathered flat buffer [world][rank_stride]
+  int packed;              // 0: whole tiles, 1: packed valid regions
+  int ph, pw;              // whole tiles
+  const long long* off;    // packed: dev [total] pixel offsets
+  long long rank_stride;   // packed: elements between two ranks' runs
+  int world;
+};
+struct TileView { const float* p; int pitch; long long plane; };
+__device__ __forceinline__ TileView tile_view(const TileSrc& s, long long k, long long t, int C, const int* r) {
+  TileView v;
+  if (s.packed) {
+    v.p = s.base + (t % s.world) * s.rank_stride + s.off[t] * C;
+    v.pitch = r[4]; v.plane = (long long)r[3] * r[4];
+  } else {
+    v.p = s.base + (size_t)k * C * s.ph * s.pw + (size_t)r[5] * s.pw + r[6];
+    v.pitch = s.pw; v.plane = (long long)s.ph * s.pw;
+  }
+  return v;
+}
+
+__global__ void k_stitch(const TileSrc src, int C, const int* __restrict__ regions, TileSeq seq,
+                         float* __restrict__ canvas, int H, int W) {
+  const long long k = blockIdx.y, t = seq.first + k * seq.stride;
   const int* r = regions + t * 8;
-  const int n = r[0], y0 = r[1], x0 = r[2], h = r[3], w = r[4], ry = r[5], rx = r[6];
+  const int n = r[0], y0 = r[1], x0 = r[2], h = r[3], w = r[4];
   const int total = h * w * C;
-  const float* tile = tiles + (size_t)t * C * ph * pw;
+  const TileView v = tile_view(src, k, t, C, r);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int c = i % C;
     const int p = i / C;
     const int x = p % w, y = p / w;
-    canvas[(((size_t)n * H + (y0 + y)) * W + (x0 + x)) * C + c] =
-        tile[((size_t)c * ph + (ry + y)) * pw + (rx + x)];
+    canvas[(((size_t)n * H + (y0 + y)) * W + (x0 + x)) * C + c] = v.p[c * v.plane + (size_t)y * v.pitch + x];
   }
 }
-hipError_t launch_stitch(const float* tiles, long long count, int C, int ph, int pw, const int* regions,
-                         float* canvas, int H, int W, hipStream_t st) {
+
+// The valid region of every tile of the sequence, [C][h][w], to its place in this rank's flat run: the crop of
+// tile_stitcher.py:38-56 applied BEFORE the collective (a 512^2 tile of a 256 grid ships 256^2 .. 384^2 pixels).
+__global__ void k_tiles_pack(const float* __restrict__ tiles, int C, int ph, int pw, const int* __restrict__ regions,
+                             const long long* __restrict__ off, TileSeq seq, float* __restrict__ flat) {
+  const long long k = blockIdx.y, t = seq.first + k * seq.stride;
+  const int* r = regions + t * 8;
+  const int h = r[3], w = r[4], ry = r[5], rx = r[6];
+  const int total = C * h * w;
+  const float* tile = tiles + (size_t)k * C * ph * pw;
+  float* dst = flat + off[t] * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int x = i % w, q = i / w, y = q % h, c = q / h;
+    dst[i] = tile[((size_t)c * ph + (ry + y)) * pw + (rx + x)];
+  }
+}
+hipError_t launch_tiles_pack(const float* tiles, int C, int ph, int pw, const int* regions, const long long* off,
+                             TileSeq seq, float* flat, hipStream_t st) {
   int gx = (ph * pw * C + 255) / 256;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(k_stitch, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, st, tiles, C, ph, pw,
-                     regions, canvas, H, W);
+  hipLaunchKernelGGL(k_tiles_pack, dim3((unsigned)gx, (unsigned)seq.count), dim3(256), 0, st, tiles, C, ph, pw, regions,
+                     off, seq, flat);
   return hipGetLastError();
 }
 
@@ -520,16 +562,16 @@ hipError_t launch_stitch(const float* tiles, long long count, int C, int ph, int
 // is pasted, every (tile, workgroup) also reduces, per channel, sum(p), sum(p^2), sum(g), sum(g^2), sum(g p),
 // min(g), max(g) of prediction p against the ground truth g at the same canvas pixels (every canvas pixel is pasted
 // exactly once).  Fixed reduction order (thread -> wave shuffles -> 4 waves): bitwise reproducible.
-// part[t][blockIdx.x][c][8] doubles; the per-frame combination (a few hundred values) is the caller's.
+// part[k][blockIdx.x][c][8] doubles; the per-frame combination (a few hundred values) is the caller's.
 constexpr int kPsnrMaxC = 4;
-__global__ __launch_bounds__(256) void k_stitch_psnr(const float* __restrict__ tiles, int C, int ph, int pw,
-                                                      const int* __restrict__ regions, float* __restrict__ canvas,
-                                                      const float* __restrict__ gt, int H, int W, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_stitch_psnr(const TileSrc src, int C, const int* __restrict__ regions, TileSeq seq,
+                                                      float* __restrict__ canvas, const float* __restrict__ gt, int H, int W,
+                                                      double* __restrict__ part) {
   __shared__ double red[4][kPsnrMaxC][7];
-  const long long t = blockIdx.y;
+  const long long k = blockIdx.y, t = seq.first + k * seq.stride;
   const int* r = regions + t * 8;
-  const int n = r[0], y0 = r[1], x0 = r[2], h = r[3], w = r[4], ry = r[5], rx = r[6];
-  const float* tile = tiles + (size_t)t * C * ph * pw;
+  const int n = r[0], y0 = r[1], x0 = r[2], h = r[3], w = r[4];
+  const TileView v = tile_view(src, k, t, C, r);
   double sp[kPsnrMaxC], spp[kPsnrMaxC], sg[kPsnrMaxC], sgg[kPsnrMaxC], sgp[kPsnrMaxC], mn[kPsnrMaxC], mx[kPsnrMaxC];
 #pragma unroll
   for (int c = 0; c < kPsnrMaxC; ++c) { sp[c] = spp[c] = sg[c] = sgg[c] = sgp[c] = 0; mn[c] = INFINITY; mx[c] = -INFINITY; }
@@ -539,7 +581,7 @@ __global__ __launch_bounds__(256) void k_stitch_psnr(const float* __restrict__ t
 #pragma unroll
     for (int c = 0; c < kPsnrMaxC; ++c) {
       if (c < C) {
-        const float p = tile[((size_t)c * ph + (ry + y)) * pw + (rx + x)];
+        const float p = v.p[c * v.plane + (size_t)y * v.pitch + x];
         const float g = gt[cpix + c];
         canvas[cpix + c] = p;
         sp[c] += p; spp[c] += (double)p * p; sg[c] += g; sgg[c] += (double)g * g; sgp[c] += (double)g * p;
@@ -561,19 +603,28 @@ __global__ __launch_bounds__(256) void k_stitch_psnr(const float* __restrict__ t
   }
   __syncthreads();
   if (threadIdx.x < C * 8) {
-    const int c = threadIdx.x >> 3, k = threadIdx.x & 7;
-    double v = 0;
-    if (k < 5) v = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
-    else if (k == 5) v = fmin(fmin(red[0][c][5], red[1][c][5]), fmin(red[2][c][5], red[3][c][5]));
-    else if (k == 6) v = fmax(fmax(red[0][c][6], red[1][c][6]), fmax(red[2][c][6], red[3][c][6]));
-    part[(((size_t)t * gridDim.x + blockIdx.x) * C + c) * 8 + k] = v;
+    const int c = threadIdx.x >> 3, kk = threadIdx.x & 7;
+    double o = 0;
+    if (kk < 5) o = (red[0][c][kk] + red[1][c][kk]) + (red[2][c][kk] + red[3][c][kk]);
+    else if (kk == 5) o = fmin(fmin(red[0][c][5], red[1][c][5]), fmin(red[2][c][5], red[3][c][5]));
+    else if (kk == 6) o = fmax(fmax(red[0][c][6], red[1][c][6]), fmax(red[2][c][6], red[3][c][6]));
+    part[(((size_t)k * gridDim.x + blockIdx.x) * C + c) * 8 + kk] = o;
   }
 }
-hipError_t launch_stitch_psnr(const float* tiles, long long count, int C, int ph, int pw, const int* regions,
-                              float* canvas, const float* gt, int H, int W, double* part, int gx, hipStream_t st) {
-  if (C < 1 || C > kPsnrMaxC || gx < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_stitch_psnr, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, st, tiles, C, ph, pw, regions,
-                     canvas, gt, H, W, part);
+// gt == nullptr: plain paste; else also the RangeInvariantPsnr partial sums (C <= 4, gx workgroups per tile)
+hipError_t launch_stitch(const StitchSrc& s, int C, const int* regions, TileSeq seq, float* canvas, int H, int W,
+                         const float* gt, double* part, int gx, hipStream_t st) {
+  const TileSrc src{s.base, s.packed, s.ph, s.pw, s.off, s.rank_stride, s.world < 1 ? 1 : s.world};
+  if (gt != nullptr) {
+    if (C < 1 || C > kPsnrMaxC || gx < 1 || part == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_stitch_psnr, dim3((unsigned)gx, (unsigned)seq.count), dim3(256), 0, st, src, C, regions, seq,
+                       canvas, gt, H, W, part);
+  } else {
+    int g = (s.ph * s.pw * C + 255) / 256;
+    if (g > 64) g = 64;
+    hipLaunchKernelGGL(k_stitch, dim3((unsigned)g, (unsigned)seq.count), dim3(256), 0, st, src, C, regions, seq, canvas,
+                       H, W);
+  }
   return hipGetLastError();
 }
 

@@ -642,10 +642,14 @@ struct dsx_exec {
   int* step_ctr = nullptr;
   float* table = nullptr;      // [6][cap]
   int table_cap = 0;
-  std::vector<float> table_host;
   bool temb_from_table = false;
   unsigned long long* loop_params = nullptr;   // device {seed, noise address}: per-call values the captured step reads
-  unsigned long long loop_params_host[2] = {0, 0};
+  // per-call host data (step table, seed, noise address) is staged in pinned memory, one slot per call in flight: a
+  // slot is reused only after the event recorded behind its copies has completed, so a second dsx_sample_loop on the
+  // same executor never overwrites bytes an earlier call's asynchronous copy has yet to read
+  struct Staging { float* host = nullptr; size_t floats = 0; hipEvent_t ev = nullptr; bool busy = false; };
+  Staging staging[4];
+  int staging_next = 0;
   hipStream_t last_stream = nullptr;           // stream of the most recent graph launches
   dsx_step_table cur_tab{};
   // graph
@@ -1166,7 +1170,10 @@ static int plan_res(dsx_exec* ex, const Module& md, const Tensor& x0, const Tens
     r = new_tensor(ex, md.cout, H, W);
     ConvSpec cr{};
     cr.w = &md.res; cr.x0 = x0; if (x1) cr.x1 = *x1; cr.out = r;
-    cr.host_fin = true;
+    // the hosted finalize reads h's GroupNorm partial sums: only when conv1's epilogue produced them (fused statistics;
+    // both planner passes agree, `planned` is set from shapes).  Otherwise c2's plan_gn adds a k_chan_stats launch
+    // AFTER this conv and the finalize must stay behind it as a launch of its own.
+    cr.host_fin = ex->stats[h.id].planned;
     if ((rc = plan_conv(ex, cr))) return rc;
   } else {
     r = x0;
@@ -1353,6 +1360,10 @@ extern "C" void dsx_exec_destroy(dsx_exec* ex) {
   if (ex->table) (void)hipFree(ex->table);
   if (ex->tp_w) (void)hipFree(ex->tp_w);
   if (ex->ws) (void)hipFree(ex->ws);
+  for (auto& sl : ex->staging) {
+    if (sl.ev) { if (sl.busy) (void)hipEventSynchronize(sl.ev); (void)hipEventDestroy(sl.ev); }
+    if (sl.host) (void)hipHostFree(sl.host);
+  }
   delete ex;
 }
 extern "C" size_t dsx_exec_workspace_bytes(const dsx_exec* ex) { return ex ? ex->ws_bytes : 0; }
@@ -1518,11 +1529,31 @@ static int ensure_table(dsx_exec* ex, const dsx_step_table* tab) {
     HIP_TRY(hipMalloc((void**)&ex->table, (size_t)6 * cap * sizeof(float)));
     ex->table_cap = cap;
   }
+  return DSX_OK;
+}
+
+// a pinned staging slot holding this call's table [6][cap] followed by {seed, noise address}; *out = its host pointer
+static int stage_call(dsx_exec* ex, const dsx_step_table* tab, uint64_t seed, const float* noise, dsx_exec::Staging** out) {
   const int cap = ex->table_cap;
-  ex->table_host.assign((size_t)6 * cap, 0.f);
+  const int T = tab->n_steps * (tab->per_sample > 0 ? tab->per_sample : 1);
+  const size_t need = (size_t)6 * cap + 4;   // + 16 bytes of loop parameters
+  dsx_exec::Staging& sl = ex->staging[ex->staging_next];
+  ex->staging_next = (ex->staging_next + 1) % 4;
+  if (sl.busy) { HIP_TRY(hipEventSynchronize(sl.ev)); sl.busy = false; }
+  if (sl.floats < need) {
+    if (sl.host) (void)hipHostFree(sl.host);
+    sl.host = nullptr; sl.floats = 0;
+    HIP_TRY(hipHostMalloc((void**)&sl.host, need * sizeof(float), hipHostMallocDefault));
+    sl.floats = need;
+  }
+  if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+  memset(sl.host, 0, (size_t)6 * cap * sizeof(float));
   const float* cols[6] = {tab->tcond, tab->a, tab->b, tab->c1, tab->c2, tab->sigma};
   for (int k = 0; k < 6; ++k)
-    if (cols[k]) memcpy(ex->table_host.data() + (size_t)k * cap, cols[k], (size_t)T * 4);
+    if (cols[k]) memcpy(sl.host + (size_t)k * cap, cols[k], (size_t)T * 4);
+  unsigned long long lp[2] = {seed, (unsigned long long)(uintptr_t)noise};
+  memcpy(sl.host + (size_t)6 * cap, lp, 16);
+  *out = &sl;
   return DSX_OK;
 }
 
@@ -1555,15 +1586,16 @@ extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const fl
   const int T = tab->n_steps;
   int rc = ensure_table(ex, tab);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(ex->table, ex->table_host.data(), (size_t)6 * ex->table_cap * 4,
-                         hipMemcpyHostToDevice, st));
+  // per-call values (step table; seed, noise address: the captured step does not bake them in) go to device memory
+  // from a pinned staging slot of this call's own
+  dsx_exec::Staging* sl = nullptr;
+  if ((rc = stage_call(ex, tab, seed, noise, &sl))) return rc;
+  HIP_TRY(hipMemcpyAsync(ex->table, sl->host, (size_t)6 * ex->table_cap * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ex->loop_params, sl->host + (size_t)6 * ex->table_cap, 16, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(sl->ev, st));
+  sl->busy = true;
   HIP_TRY(hipMemsetAsync(ex->step_ctr, 0, 4, st));
   if ((rc = load_inputs(ex, cond, x, ex->x_c, 0, st))) return rc;
-
-  // per-call values (seed, noise address) go to device memory: the captured step does not bake them in
-  ex->loop_params_host[0] = seed;
-  ex->loop_params_host[1] = (unsigned long long)(uintptr_t)noise;
-  HIP_TRY(hipMemcpyAsync(ex->loop_params, ex->loop_params_host, 16, hipMemcpyHostToDevice, st));
 
   const size_t snap_elems = (size_t)ex->B * ex->x_c * ex->H * ex->W;
   bool graph_ok = false;
@@ -1754,14 +1786,21 @@ extern "C" int dsx_tile_regions(const int64_t data_shape[3], const int64_t grid_
   return DSX_OK;
 }
 
-extern "C" int dsx_tiles_gather(const float* frames, const int64_t data_shape[3], const int64_t patch_shape[3],
-                                const int64_t* patch_start, const int64_t* tile_ids, int64_t count,
-                                float* tiles, void* stream) {
-  if (!frames || !data_shape || !patch_shape || !patch_start || !tiles || count < 0)
-    return fail(DSX_ERR_INVALID, "bad argument");
-  if (count == 0) return DSX_OK;
-  hipStream_t st = (hipStream_t)stream;
-  std::vector<int> starts((size_t)count * 3);
+// ---- legacy per-call forms: the caller passes host tables, which are uploaded for the call (one small allocation,
+// one synchronous copy, freed on every path).  The stall-free forms are the dsx_tileplan_* entry points below.
+namespace {
+struct DevTemp {           // a device buffer for the duration of one call
+  void* p = nullptr;
+  ~DevTemp() { if (p) (void)hipFree(p); }
+  hipError_t upload(const void* host, size_t bytes) {
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    return hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
+  }
+};
+static int check_starts(const int64_t* patch_start, const int64_t* tile_ids, int64_t count, const int64_t data_shape[3],
+                        const int64_t patch_shape[3], std::vector<int>& starts) {
+  starts.resize((size_t)count * 3);
   for (int64_t i = 0; i < count; ++i) {
     const int64_t id = tile_ids ? tile_ids[i] : i;
     for (int d = 0; d < 3; ++d) starts[i * 3 + d] = (int)patch_start[id * 3 + d];
@@ -1770,14 +1809,33 @@ extern "C" int dsx_tiles_gather(const float* frames, const int64_t data_shape[3]
         starts[i * 3 + 2] + patch_shape[2] > data_shape[2])
       return fail(DSX_ERR_INVALID, "tile %lld lies outside the frames", (long long)id);
   }
-  int* d_starts = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_starts, starts.size() * 4));
-  HIP_TRY(hipMemcpyAsync(d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));  // `starts` is a stack-owned host buffer
-  HIP_TRY(launch_tiles_gather(frames, (int)data_shape[1], (int)data_shape[2], (int)patch_shape[1],
-                              (int)patch_shape[2], d_starts, count, tiles, st));
-  HIP_TRY(hipFree(d_starts));  // synchronises: the gather has finished
   return DSX_OK;
+}
+static int check_regions(const int32_t* regions, int64_t count, const int64_t data_shape[3], int ph, int pw) {
+  for (int64_t i = 0; i < count; ++i) {
+    const int32_t* r = regions + i * 8;
+    if (r[0] < 0 || r[0] >= data_shape[0] || r[1] < 0 || r[1] + r[3] > data_shape[1] || r[2] < 0 ||
+        r[2] + r[4] > data_shape[2] || r[5] < 0 || r[5] + r[3] > ph || r[6] < 0 || r[6] + r[4] > pw)
+      return fail(DSX_ERR_INVALID, "region %lld out of bounds", (long long)i);
+  }
+  return DSX_OK;
+}
+}  // namespace
+
+extern "C" int dsx_tiles_gather(const float* frames, const int64_t data_shape[3], const int64_t patch_shape[3],
+                                const int64_t* patch_start, const int64_t* tile_ids, int64_t count,
+                                float* tiles, void* stream) {
+  if (!frames || !data_shape || !patch_shape || !patch_start || !tiles || count < 0)
+    return fail(DSX_ERR_INVALID, "bad argument");
+  if (count == 0) return DSX_OK;
+  std::vector<int> starts;
+  int rc = check_starts(patch_start, tile_ids, count, data_shape, patch_shape, starts);
+  if (rc) return rc;
+  DevTemp d;
+  HIP_TRY(d.upload(starts.data(), starts.size() * 4));
+  HIP_TRY(launch_tiles_gather(frames, (int)data_shape[1], (int)data_shape[2], (int)patch_shape[1],
+                              (int)patch_shape[2], (const int*)d.p, TileSeq{0, 1, count}, tiles, (hipStream_t)stream));
+  return DSX_OK;   // ~DevTemp: hipFree waits for the launch
 }
 
 extern "C" int dsx_stitch(const float* tiles, int64_t count, int C, int ph, int pw, const int32_t* regions,
@@ -1785,19 +1843,13 @@ extern "C" int dsx_stitch(const float* tiles, int64_t count, int C, int ph, int 
   if (!tiles || !regions || !canvas || !data_shape || count < 0 || C < 1)
     return fail(DSX_ERR_INVALID, "bad argument");
   if (count == 0) return DSX_OK;
-  hipStream_t st = (hipStream_t)stream;
-  for (int64_t i = 0; i < count; ++i) {
-    const int32_t* r = regions + i * 8;
-    if (r[0] < 0 || r[0] >= data_shape[0] || r[1] < 0 || r[1] + r[3] > data_shape[1] || r[2] < 0 ||
-        r[2] + r[4] > data_shape[2] || r[5] < 0 || r[5] + r[3] > ph || r[6] < 0 || r[6] + r[4] > pw)
-      return fail(DSX_ERR_INVALID, "region %lld out of bounds", (long long)i);
-  }
-  int* d_reg = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_reg, (size_t)count * 32));
-  HIP_TRY(hipMemcpyAsync(d_reg, regions, (size_t)count * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(launch_stitch(tiles, count, C, ph, pw, d_reg, canvas, (int)data_shape[1], (int)data_shape[2], st));
-  HIP_TRY(hipFree(d_reg));  // synchronises: the paste has finished
+  int rc = check_regions(regions, count, data_shape, ph, pw);
+  if (rc) return rc;
+  DevTemp d;
+  HIP_TRY(d.upload(regions, (size_t)count * 32));
+  const StitchSrc src{tiles, 0, ph, pw, nullptr, 0, 1};
+  HIP_TRY(launch_stitch(src, C, (const int*)d.p, TileSeq{0, 1, count}, canvas, (int)data_shape[1], (int)data_shape[2],
+                        nullptr, nullptr, 0, (hipStream_t)stream));
   return DSX_OK;
 }
 
@@ -1812,20 +1864,13 @@ extern "C" int dsx_stitch_psnr(const float* tiles, int64_t count, int C, int ph,
   if (!tiles || !regions || !canvas || !data_shape || !gt_canvas || !partials_dev || count < 0 || C < 1 || C > 4)
     return fail(DSX_ERR_INVALID, "bad argument (1 <= C <= 4)");
   if (count == 0) return DSX_OK;
-  hipStream_t st = (hipStream_t)stream;
-  for (int64_t i = 0; i < count; ++i) {
-    const int32_t* r = regions + i * 8;
-    if (r[0] < 0 || r[0] >= data_shape[0] || r[1] < 0 || r[1] + r[3] > data_shape[1] || r[2] < 0 ||
-        r[2] + r[4] > data_shape[2] || r[5] < 0 || r[5] + r[3] > ph || r[6] < 0 || r[6] + r[4] > pw)
-      return fail(DSX_ERR_INVALID, "region %lld out of bounds", (long long)i);
-  }
-  int* d_reg = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_reg, (size_t)count * 32));
-  HIP_TRY(hipMemcpyAsync(d_reg, regions, (size_t)count * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(launch_stitch_psnr(tiles, count, C, ph, pw, d_reg, canvas, gt_canvas, (int)data_shape[1], (int)data_shape[2],
-                             partials_dev, dsx_stitch_psnr_blocks(ph, pw), st));
-  HIP_TRY(hipFree(d_reg));
+  int rc = check_regions(regions, count, data_shape, ph, pw);
+  if (rc) return rc;
+  DevTemp d;
+  HIP_TRY(d.upload(regions, (size_t)count * 32));
+  const StitchSrc src{tiles, 0, ph, pw, nullptr, 0, 1};
+  HIP_TRY(launch_stitch(src, C, (const int*)d.p, TileSeq{0, 1, count}, canvas, (int)data_shape[1], (int)data_shape[2],
+                        gt_canvas, partials_dev, dsx_stitch_psnr_blocks(ph, pw), (hipStream_t)stream));
   return DSX_OK;
 }
 
@@ -1839,23 +1884,193 @@ extern "C" int dsx_tiles_gather_norm(const float* frames0, const float* frames1,
     return fail(DSX_ERR_INVALID, "bad argument");
   if (norm[1] == 0.0 || norm[3] == 0.0 || norm[5] == 0.0) return fail(DSX_ERR_INVALID, "zero standard deviation");
   if (count == 0) return DSX_OK;
-  hipStream_t st = (hipStream_t)stream;
-  std::vector<int> starts((size_t)count * 3);
-  for (int64_t i = 0; i < count; ++i) {
-    const int64_t id = tile_ids ? tile_ids[i] : i;
-    for (int d = 0; d < 3; ++d) starts[i * 3 + d] = (int)patch_start[id * 3 + d];
-    if (starts[i * 3] < 0 || starts[i * 3] >= data_shape[0] || starts[i * 3 + 1] < 0 ||
-        starts[i * 3 + 1] + patch_shape[1] > data_shape[1] || starts[i * 3 + 2] < 0 ||
-        starts[i * 3 + 2] + patch_shape[2] > data_shape[2])
-      return fail(DSX_ERR_INVALID, "tile %lld lies outside the frames", (long long)id);
-  }
-  int* d_starts = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_starts, starts.size() * 4));
-  HIP_TRY(hipMemcpyAsync(d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<int> starts;
+  int rc = check_starts(patch_start, tile_ids, count, data_shape, patch_shape, starts);
+  if (rc) return rc;
+  DevTemp d;
+  HIP_TRY(d.upload(starts.data(), starts.size() * 4));
   HIP_TRY(launch_tiles_gather_norm(frames0, frames1, (int)data_shape[1], (int)data_shape[2], (int)patch_shape[1],
-                                   (int)patch_shape[2], d_starts, count, w0, w1, norm, from_norm_target, tiles_in,
-                                   tiles_target, st));
-  HIP_TRY(hipFree(d_starts));
+                                   (int)patch_shape[2], (const int*)d.p, TileSeq{0, 1, count}, w0, w1, norm,
+                                   from_norm_target, tiles_in, tiles_target, (hipStream_t)stream));
+  return DSX_OK;
+}
+
+// ------------------------------------------------------------------ tile plan with device-resident tables
+// One handle per (data, grid, patch, mode): patch starts and valid regions of every tile are uploaded ONCE; every call
+// names its tiles as the arithmetic sequence first, first + stride, ... (a rank's shard r, r + W, ... or a batch of
+// it) and the kernels index the plan's tables by tile id.  No allocation, copy or synchronisation per call.
+struct dsx_tileplan {
+  TilePlanner t;
+  int64_t total = 0;
+  std::vector<int32_t> starts, regions;          // [total][3], [total][8]
+  int* d_starts = nullptr;                       // one device allocation: starts, then regions
+  int* d_regions = nullptr;
+  struct Offsets {                               // pack layout for `world` ranks (dsx_tileplan_pack_layout)
+    int world = 0;
+    std::vector<int64_t> off, rank_pixels;
+    long long* d_off = nullptr;
+  };
+  std::vector<Offsets> offs;
+};
+
+static void plan_layout(const dsx_tileplan* p, int world, dsx_tileplan::Offsets& o) {
+  o.world = world;
+  o.off.assign((size_t)p->total, 0);
+  o.rank_pixels.assign((size_t)world, 0);
+  for (int64_t id = 0; id < p->total; ++id) {    // rank q's run: its tiles q, q + world, ... back to back
+    const int q = (int)(id % world);
+    o.off[id] = o.rank_pixels[q];
+    o.rank_pixels[q] += (int64_t)p->regions[id * 8 + 3] * p->regions[id * 8 + 4];
+  }
+}
+
+extern "C" int dsx_tileplan_create(const int64_t data_shape[3], const int64_t grid_shape[3], const int64_t patch_shape[3],
+                                   int mode, dsx_tileplan** out) {
+  if (!out) return fail(DSX_ERR_INVALID, "null argument");
+  auto p = std::make_unique<dsx_tileplan>();
+  int rc = make_planner(data_shape, grid_shape, patch_shape, mode, p->t);
+  if (rc) return rc;
+  for (int d = 0; d < 3; ++d)
+    if (data_shape[d] >= (1LL << 31)) return fail(DSX_ERR_INVALID, "data extent exceeds 32 bits");
+  p->total = p->t.total();
+  p->starts.resize((size_t)p->total * 3);
+  p->regions.resize((size_t)p->total * 8);
+  std::vector<int64_t> ps((size_t)p->total * 3);
+  if (p->total) {
+    if (dsx_tile_plan(data_shape, grid_shape, patch_shape, mode, nullptr, ps.data(), p->total) < 0) return DSX_ERR_INVALID;
+    rc = dsx_tile_regions(data_shape, grid_shape, patch_shape, mode, p->regions.data(), p->total);
+    if (rc) return rc;
+    for (int64_t i = 0; i < p->total; ++i) {
+      for (int d = 0; d < 3; ++d) p->starts[i * 3 + d] = (int32_t)ps[i * 3 + d];
+      if (ps[i * 3] < 0 || ps[i * 3] >= data_shape[0] || ps[i * 3 + 1] < 0 || ps[i * 3 + 1] + patch_shape[1] > data_shape[1] ||
+          ps[i * 3 + 2] < 0 || ps[i * 3 + 2] + patch_shape[2] > data_shape[2])
+        return fail(DSX_ERR_INVALID, "tile %lld lies outside the frames (this tiling mode needs padded frames)", (long long)i);
+    }
+    rc = check_regions(p->regions.data(), p->total, data_shape, (int)patch_shape[1], (int)patch_shape[2]);
+    if (rc) return rc;
+  }
+  *out = p.release();
+  return DSX_OK;
+}
+extern "C" void dsx_tileplan_destroy(dsx_tileplan* p) {
+  if (!p) return;
+  if (p->d_starts) (void)hipFree(p->d_starts);
+  for (auto& o : p->offs) if (o.d_off) (void)hipFree(o.d_off);
+  delete p;
+}
+extern "C" int64_t dsx_tileplan_total(const dsx_tileplan* p) { return p ? p->total : 0; }
+
+// host only: pixel offset of every tile inside its rank's packed run and the pixels of every rank's run
+extern "C" int dsx_tileplan_pack_layout(const dsx_tileplan* p, int world, int64_t* off, int64_t* rank_pixels) {
+  if (!p || world < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  dsx_tileplan::Offsets o;
+  plan_layout(p, world, o);
+  if (off) memcpy(off, o.off.data(), o.off.size() * 8);
+  if (rank_pixels) memcpy(rank_pixels, o.rank_pixels.data(), o.rank_pixels.size() * 8);
+  return DSX_OK;
+}
+
+static int plan_device(dsx_tileplan* p) {       // first device use: upload the tables (once)
+  if (p->d_starts || p->total == 0) return DSX_OK;
+  const size_t nb = (size_t)p->total * (3 + 8) * 4;
+  HIP_TRY(hipMalloc((void**)&p->d_starts, nb));
+  p->d_regions = p->d_starts + p->total * 3;
+  hipError_t e = hipMemcpy(p->d_starts, p->starts.data(), (size_t)p->total * 12, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_regions, p->regions.data(), (size_t)p->total * 32, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(p->d_starts); p->d_starts = nullptr; p->d_regions = nullptr;
+    return fail(DSX_ERR_HIP, "upload of the tile tables failed: %s", hipGetErrorString(e));
+  }
+  return DSX_OK;
+}
+static int plan_offsets(dsx_tileplan* p, int world, const dsx_tileplan::Offsets** out) {
+  for (auto& o : p->offs) if (o.world == world) { *out = &o; return DSX_OK; }
+  dsx_tileplan::Offsets o;
+  plan_layout(p, world, o);
+  if (p->total) {
+    HIP_TRY(hipMalloc((void**)&o.d_off, (size_t)p->total * 8));
+    hipError_t e = hipMemcpy(o.d_off, o.off.data(), (size_t)p->total * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(o.d_off); return fail(DSX_ERR_HIP, "upload of the pack offsets failed"); }
+  }
+  p->offs.push_back(std::move(o));
+  *out = &p->offs.back();
+  return DSX_OK;
+}
+static int seq_ok(const dsx_tileplan* p, int64_t first, int64_t stride, int64_t count) {
+  if (first < 0 || stride < 1 || count < 0) return fail(DSX_ERR_INVALID, "bad tile sequence");
+  if (count > 0 && first + (count - 1) * stride >= p->total) return fail(DSX_ERR_INVALID, "tile sequence leaves the plan (%lld tiles)", (long long)p->total);
+  if (count > 65535) return fail(DSX_ERR_INVALID, "at most 65535 tiles per call");
+  return DSX_OK;
+}
+
+extern "C" int dsx_tileplan_gather(dsx_tileplan* p, const float* frames, int64_t first, int64_t stride, int64_t count,
+                                   float* tiles, void* stream) {
+  if (!p || !frames || !tiles) return fail(DSX_ERR_INVALID, "null argument");
+  int rc = seq_ok(p, first, stride, count);
+  if (rc || count == 0) return rc;
+  if ((rc = plan_device(p))) return rc;
+  HIP_TRY(launch_tiles_gather(frames, (int)p->t.D[1], (int)p->t.D[2], (int)p->t.p[1], (int)p->t.p[2], p->d_starts,
+                              TileSeq{first, stride, count}, tiles, (hipStream_t)stream));
+  return DSX_OK;
+}
+extern "C" int dsx_tileplan_gather_norm(dsx_tileplan* p, const float* frames0, const float* frames1, int64_t first,
+                                        int64_t stride, int64_t count, float w0, float w1, const double norm[6],
+                                        int from_norm_target, float* tiles_in, float* tiles_target, void* stream) {
+  if (!p || !frames0 || !frames1 || !norm || !tiles_in || !tiles_target) return fail(DSX_ERR_INVALID, "null argument");
+  if (norm[1] == 0.0 || norm[3] == 0.0 || norm[5] == 0.0) return fail(DSX_ERR_INVALID, "zero standard deviation");
+  int rc = seq_ok(p, first, stride, count);
+  if (rc || count == 0) return rc;
+  if ((rc = plan_device(p))) return rc;
+  HIP_TRY(launch_tiles_gather_norm(frames0, frames1, (int)p->t.D[1], (int)p->t.D[2], (int)p->t.p[1], (int)p->t.p[2],
+                                   p->d_starts, TileSeq{first, stride, count}, w0, w1, norm, from_norm_target, tiles_in,
+                                   tiles_target, (hipStream_t)stream));
+  return DSX_OK;
+}
+// paste whole predicted tiles (count, C, ph, pw) of the sequence; gt_canvas != NULL: also the PSNR partial sums
+// (count * dsx_stitch_psnr_blocks * C * 8 doubles, as dsx_stitch_psnr)
+extern "C" int dsx_tileplan_stitch(dsx_tileplan* p, const float* tiles, int C, int64_t first, int64_t stride, int64_t count,
+                                   float* canvas, const float* gt_canvas, double* partials_dev, void* stream) {
+  if (!p || !tiles || !canvas || C < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  if (gt_canvas && (!partials_dev || C > 4)) return fail(DSX_ERR_INVALID, "PSNR sums need a partials buffer and C <= 4");
+  int rc = seq_ok(p, first, stride, count);
+  if (rc || count == 0) return rc;
+  if ((rc = plan_device(p))) return rc;
+  const int ph = (int)p->t.p[1], pw = (int)p->t.p[2];
+  const StitchSrc src{tiles, 0, ph, pw, nullptr, 0, 1};
+  HIP_TRY(launch_stitch(src, C, p->d_regions, TileSeq{first, stride, count}, canvas, (int)p->t.D[1], (int)p->t.D[2],
+                        gt_canvas, partials_dev, dsx_stitch_psnr_blocks(ph, pw), (hipStream_t)stream));
+  return DSX_OK;
+}
+// valid regions of the sequence's predicted tiles -> this rank's packed run (`flat_rank`: the start of the run of rank
+// first % world; tiles land at their final offsets, so batches of a shard pack into one buffer independently)
+extern "C" int dsx_tileplan_pack(dsx_tileplan* p, const float* tiles, int C, int world, int64_t first, int64_t count,
+                                 float* flat_rank, void* stream) {
+  if (!p || !tiles || !flat_rank || C < 1 || world < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  int rc = seq_ok(p, first, world, count);
+  if (rc || count == 0) return rc;
+  if ((rc = plan_device(p))) return rc;
+  const dsx_tileplan::Offsets* o = nullptr;
+  if ((rc = plan_offsets(p, world, &o))) return rc;
+  HIP_TRY(launch_tiles_pack(tiles, C, (int)p->t.p[1], (int)p->t.p[2], p->d_regions, o->d_off, TileSeq{first, world, count},
+                            flat_rank, (hipStream_t)stream));
+  return DSX_OK;
+}
+// paste ALL tiles from the gathered exchange buffer [world][rank_stride_elems] (rank q's run at q * rank_stride_elems)
+extern "C" int dsx_tileplan_paste_packed(dsx_tileplan* p, const float* flat_all, int C, int world, int64_t rank_stride_elems,
+                                         float* canvas, const float* gt_canvas, double* partials_dev, void* stream) {
+  if (!p || !flat_all || !canvas || C < 1 || world < 1) return fail(DSX_ERR_INVALID, "bad argument");
+  if (gt_canvas && (!partials_dev || C > 4)) return fail(DSX_ERR_INVALID, "PSNR sums need a partials buffer and C <= 4");
+  if (p->total == 0) return DSX_OK;
+  int rc = seq_ok(p, 0, 1, p->total);
+  if (rc) return rc;
+  if ((rc = plan_device(p))) return rc;
+  const dsx_tileplan::Offsets* o = nullptr;
+  if ((rc = plan_offsets(p, world, &o))) return rc;
+  for (int q = 0; q < world; ++q)
+    if (o->rank_pixels[q] * C > rank_stride_elems) return fail(DSX_ERR_INVALID, "rank stride smaller than rank %d's run", q);
+  const int ph = (int)p->t.p[1], pw = (int)p->t.p[2];
+  const StitchSrc src{flat_all, 1, ph, pw, o->d_off, rank_stride_elems, world};
+  HIP_TRY(launch_stitch(src, C, p->d_regions, TileSeq{0, 1, p->total}, canvas, (int)p->t.D[1], (int)p->t.D[2], gt_canvas,
+                        partials_dev, dsx_stitch_psnr_blocks(ph, pw), (hipStream_t)stream));
   return DSX_OK;
 }

@@ -143,7 +143,7 @@ class UNetEngine:
             self._finalized_dtype = code
 
     # ---- packed-weight cache (N4: the repack next to `*_gen.pth`, model/model.py:153-166) -------------------
-    _PACK_MAGIC = b"DSXPACK2"
+    _PACK_MAGIC = b"DSXPACK3"
 
     def _pack_header(self, dtype_code_, key):
         import hashlib
@@ -159,9 +159,11 @@ class UNetEngine:
         check(lib.dsx_model_packed_bytes(self._h, self._finalized_dtype, C.byref(n)))
         buf = np.empty(n.value, dtype=np.uint8)
         check(lib.dsx_model_export_packed(self._h, buf.ctypes.data_as(C.c_void_p), n.value))
+        import hashlib
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as f:
             f.write(self._pack_header(self._finalized_dtype, key))
+            f.write(hashlib.sha256(buf.data).digest())               # of the payload: a damaged file is refused
             buf.tofile(f)
         os.replace(tmp, path)
 
@@ -175,12 +177,16 @@ class UNetEngine:
         n = C.c_size_t()
         check(lib.dsx_model_packed_bytes(self._h, code, C.byref(n)))
         hdr = self._pack_header(code, key)
-        if os.path.getsize(path) != len(hdr) + n.value:
+        import hashlib
+        if os.path.getsize(path) != len(hdr) + 32 + n.value:
             return False
         with open(path, "rb") as f:
             if f.read(len(hdr)) != hdr:
                 return False
+            digest = f.read(32)
             buf = np.fromfile(f, dtype=np.uint8, count=n.value)
+        if buf.size != n.value or hashlib.sha256(buf.data).digest() != digest:
+            return False
         self._drop_execs()
         check(lib.dsx_model_finalize_packed(self._h, code, buf.ctypes.data_as(C.c_void_p), n.value))
         self._finalized_dtype = code

@@ -34,7 +34,7 @@ class EngineUNet(nn.Module):
         self.compute_dtype = "f32"
         self._synced = None
         # packed-weight cache (set by DDPM.load_network): file prefix and the checkpoint's hash
-        self.pack_cache = None          # (path_prefix, key) or None
+        self.pack_cache = None          # (path_prefix, key[, tensor fingerprint]) or None; consumed by the next sync
         self.pack_cache_hit = None      # True / False after the last engine() sync that consulted the cache
         g = torch.Generator().manual_seed(0)
         self._ref_names = list(self._eng.param_names)
@@ -84,6 +84,11 @@ class EngineUNet(nn.Module):
         self._synced = None
 
     # ---- engine sync -----------------------------------------------------------------------
+    def attach_pack_cache(self, prefix, key):
+        """DDPM.load_network: a packed image of exactly the weights just loaded may be found at / written to
+        ``<prefix>.<dtype>.dsxpack``."""
+        self.pack_cache = (prefix, key, self._fingerprint()[1:])
+
     def _fingerprint(self):
         return (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self._tensors().values())
 
@@ -92,8 +97,13 @@ class EngineUNet(nn.Module):
         fp = self._fingerprint()
         if self._synced != fp:
             hit = False
-            if self.pack_cache is not None:
-                prefix, key = self.pack_cache
+            # the cache describes the checkpoint as load_network read it: honoured once, and only while the module's
+            # tensors are still the ones it was attached to (an in-place edit afterwards repacks from the tensors)
+            cache, self.pack_cache = self.pack_cache, None
+            if cache is not None and len(cache) == 3 and cache[2] != fp[1:]:
+                cache = None
+            if cache is not None:
+                prefix, key = cache[0], cache[1]
                 path = f"{prefix}.{self.compute_dtype}.dsxpack"
                 hit = self._eng.finalize_from_packed(path, self.compute_dtype, key)
                 if not hit:

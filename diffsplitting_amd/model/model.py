@@ -91,6 +91,6 @@ class DDPM(BaseModel):
             key = h.hexdigest()
             k = 0
             for m in self.netG.modules():
-                if hasattr(m, "pack_cache"):
-                    m.pack_cache = ("{}_gen.unet{}".format(load_path, k), key)
+                if hasattr(m, "attach_pack_cache"):
+                    m.attach_pack_cache("{}_gen.unet{}".format(load_path, k), key)
                     k += 1

@@ -38,6 +38,11 @@ class _SamplerBase(nn.Module):
     def get_current_log(self):
         return {}
 
+    @property
+    def prediction_channels(self):
+        """Channels of ``last_full_batch`` (what tiled prediction stitches)."""
+        return int(getattr(self, "out_channel", None) or self.channels)
+
 
 class GaussianSampler(_SamplerBase):
     """SR3 / DDPM ancestral sampling (sr3 diffusion.py:141-213, ddpm diffusion.py:194-247)."""
@@ -253,6 +258,10 @@ class JointIndiSampler(_SamplerBase):
         self.scale_param = nn.Parameter(torch.tensor(1.0))
         self.w_input_loss = w_input_loss
         self._streams = None
+
+    @property
+    def prediction_channels(self):
+        return self.indi1.prediction_channels + self.indi2.prediction_channels   # joint_indi.py:135 (channel cat)
 
     def set_loss(self, device):
         self.indi1.set_loss(device)

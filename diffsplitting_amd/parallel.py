@@ -45,30 +45,61 @@ def self_launch(n, argv, timeout=None):
     """Start ``n`` fresh children ``python argv...`` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
     rendezvous on 127.0.0.1) and wait for them.  Must be called BEFORE this process touches the GPU: the children
     are new processes (never an exec of a process that has initialised HIP).  Rank 0's stdout is forwarded to ours,
-    every rank's stderr to ours; returns 0 only if every child exited 0."""
+    every rank's stderr to ours.  All children are watched together: the first non-zero exit (or the timeout) ends
+    the others, so a rank that dies before the rendezvous does not leave its peers waiting for it.  Returns 0 only if
+    every child exited 0."""
+    import threading
+    import time
     n = int(n)
     port = free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
-    out0, _ = procs[0].communicate(timeout=timeout)
-    rcs = [procs[0].returncode] + [p.wait(timeout=timeout) for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0.decode(errors="replace"))
-        sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"[self_launch] ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        for p in procs:
+    out0 = []
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+        drain = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+        drain.start()
+        deadline = None if timeout is None else time.monotonic() + float(timeout)
+        bad, timed_out = [], False
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad or all(rc is not None for rc in rcs):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                timed_out = True
+                break
+            time.sleep(0.05)
+        if bad or timed_out:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.monotonic() + 5.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        drain.join(timeout=10)
+        if out0 and out0[0]:
+            sys.stdout.write(out0[0].decode(errors="replace"))
+            sys.stdout.flush()
+        if timed_out:
+            print(f"[self_launch] timed out after {timeout} s: the ranks were stopped", file=sys.stderr)
+            return 1
+        if bad:
+            print(f"[self_launch] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+            return 1
+        return 0
+    finally:
+        for p in procs:                       # whatever happened above: no child outlives this call
             if p.poll() is None:
                 p.kill()
-        return 1
-    return 0
 
 
 def rank():
@@ -107,6 +138,17 @@ def all_gather_tiles(local, total, group=None):
     # rank q's k-th tile has id q + k*world  ->  interleave back to id order
     full = out.transpose(0, 1).reshape((per * world,) + tuple(local.shape[1:]))
     return full[:total].contiguous()
+
+
+def all_gather_flat(flat, group=None):
+    """The tiled path's one collective: every rank's packed run of CROPPED tiles (equal-sized 1-D tensors,
+    ``TilePlan.rank_stride`` elements) -> (world, rank_stride) on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return flat.view(1, -1)
+    out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat.contiguous().view(-1), group=group)
+    return out.view(world, -1)
 
 
 def all_gather_batch(x, group=None):

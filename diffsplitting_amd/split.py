@@ -22,6 +22,7 @@ import torch
 from . import parallel
 from .core import logger as Logger
 from .data.split_dataset import DataLocation, SplitDatasetTiledPred
+from .data.tiled_predict import TileExchange
 from .model import create_model
 
 
@@ -95,22 +96,18 @@ def main(argv=None):
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs, tars = [], []
+    # every rank holds the frames: the ground truth needs no tiles and no collective
+    C_out = netG.prediction_channels
+    gt = val_set.normalized_target_frames()                           # (N,H,W,C_target), normalised
+    score = gt.shape[-1] == C_out and C_out <= 4
+    ex = TileExchange(plan, C_out, dev, gt=gt if score else None)
     for i in range(0, len(ids), args.batch_tiles):
-        batch = val_set.tiles(ids[i:i + args.batch_tiles])
+        chunk = ids[i:i + args.batch_tiles]
+        batch = val_set.tiles(chunk)
         netG.inference(batch["input"], continuous=False, num_timesteps=n_steps)
-        outs.append(netG.last_full_batch.clone())
-        tars.append(batch["target"])
-    C_out = netG.last_full_batch.shape[1] if outs else 1
-    local = torch.cat(outs) if outs else torch.zeros((0, C_out, patch, patch), device=dev)
-    ltar = torch.cat(tars) if tars else torch.zeros((0, 2, patch, patch), device=dev)
-    full = parallel.all_gather_tiles(local, plan.total)              # the path's only collective
-    gt_tiles = parallel.all_gather_tiles(ltar, plan.total)
-    gt = plan.stitch(gt_tiles)                                        # the normalised targets, (N,H,W,2)
-    if full.shape[1] == gt.shape[-1] and full.shape[1] <= 4:
-        pred, ps = plan.stitch_with_psnr(full, gt)                    # metric accumulated while pasting
-    else:
-        pred, ps = plan.stitch(full), None
+        ex.add(netG.last_full_batch, chunk)
+    res = ex.finish()                                                 # the path's only collective: cropped tiles
+    pred, ps = res if score else (res, None)                          # metric accumulated while pasting
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

@@ -260,6 +260,43 @@ int dsx_stitch_psnr(const float* tiles_dev, int64_t count, int C, int ph, int pw
                     float* canvas_dev, const int64_t data_shape[3], const float* gt_canvas_dev, double* partials_dev,
                     void* stream);
 
+/* ------------------------------------------------- tile plan with device-resident tables (the stall-free forms)
+ * The entry points above take host tables and upload them per call (a small allocation and a synchronous copy each).
+ * A dsx_tileplan keeps the patch starts and valid regions of every tile on the device (uploaded once, at first
+ * device use); every call names its tiles as the arithmetic sequence first, first + stride, ... (count terms) -- the
+ * shard r, r + W, r + 2W, ... of rank r, or a batch of it -- and the kernels index the tables by tile id: no
+ * allocation, copy or synchronisation per call.  Replaces SplitDatasetTiledPred's per-index TileIndexManager lookups
+ * (data/split_dataset_tiledpred.py:9-32) and stitch_predictions (data/tile_stitcher.py:10-81) for batch dispatch. */
+typedef struct dsx_tileplan dsx_tileplan;
+int dsx_tileplan_create(const int64_t data_shape[3], const int64_t grid_shape[3], const int64_t patch_shape[3],
+                        int tiling_mode, dsx_tileplan** out);        /* host only; fails if a tile leaves the frames */
+void dsx_tileplan_destroy(dsx_tileplan* plan);
+int64_t dsx_tileplan_total(const dsx_tileplan* plan);
+/* dsx_tiles_gather / dsx_tiles_gather_norm for the tiles first + k*stride, k < count (<= 65535 per call) */
+int dsx_tileplan_gather(dsx_tileplan* plan, const float* frames_dev, int64_t first, int64_t stride, int64_t count,
+                        float* tiles_dev, void* stream);
+int dsx_tileplan_gather_norm(dsx_tileplan* plan, const float* frames0_dev, const float* frames1_dev, int64_t first,
+                             int64_t stride, int64_t count, float w0, float w1, const double norm[6],
+                             int from_norm_target, float* tiles_in_dev, float* tiles_target_dev, void* stream);
+/* dsx_stitch (gt_canvas_dev == NULL) or dsx_stitch_psnr for whole predicted tiles (count, C, ph, pw) of the sequence */
+int dsx_tileplan_stitch(dsx_tileplan* plan, const float* tiles_dev, int C, int64_t first, int64_t stride, int64_t count,
+                        float* canvas_dev, const float* gt_canvas_dev, double* partials_dev, void* stream);
+/* Multi-GPU exchange of CROPPED tiles (the crop of tile_stitcher.py:38-56 applied before the collective).
+ * Rank q of `world` owns the tiles q, q + world, ...; its packed run holds their valid regions [C][h][w] back to back
+ * in id order.  dsx_tileplan_pack_layout (host only) gives the pixel offset of every tile inside its rank's run and
+ * the pixels of every rank's run (multiply by C for elements); the collective ships max(rank run) elements per rank
+ * instead of whole (C, ph, pw) tiles.
+ *   dsx_tileplan_pack        : tiles first, first + world, ... (count of them, (count, C, ph, pw)) -> their places in
+ *                              flat_rank_dev, the run of rank first % world
+ *   dsx_tileplan_paste_packed: every tile of the plan from the gathered buffer [world][rank_stride_elems] into the
+ *                              canvas (N,H,W,C); with gt_canvas_dev also the PSNR partial sums (total * blocks * C * 8) */
+int dsx_tileplan_pack_layout(const dsx_tileplan* plan, int world, int64_t* tile_offset_pixels /*[total]*/,
+                             int64_t* rank_pixels /*[world]*/);
+int dsx_tileplan_pack(dsx_tileplan* plan, const float* tiles_dev, int C, int world, int64_t first, int64_t count,
+                      float* flat_rank_dev, void* stream);
+int dsx_tileplan_paste_packed(dsx_tileplan* plan, const float* flat_all_dev, int C, int world, int64_t rank_stride_elems,
+                              float* canvas_dev, const float* gt_canvas_dev, double* partials_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

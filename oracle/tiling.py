@@ -105,3 +105,40 @@ def extract_patch(frames, plan, idx):
     n, y, x = plan.patch_location(idx)
     p = plan.patch_shape
     return np.moveaxis(frames[n, y:y + p[1], x:x + p[2], :], -1, 0)
+
+
+# ---- the cropped multi-rank exchange: valid regions packed per rank, one all-gather, paste --------------
+def pack_layout(plan, world):
+    """Pixel offset of every tile inside its rank's packed run (rank = id % world, tiles in id order) and the pixels
+    of every rank's run: the crop of tile_stitcher.py:38-56 applied before the collective."""
+    T = plan.total()
+    off = np.zeros(T, dtype=np.int64)
+    runs = np.zeros(world, dtype=np.int64)
+    for i in range(T):
+        vgs, vge, _, _ = plan.valid_region(i)
+        off[i] = runs[i % world]
+        runs[i % world] += int(vge[1] - vgs[1]) * int(vge[2] - vgs[2])
+    return off, runs
+
+
+def pack_rank(predictions, ids, plan, off, run_elems):
+    """predictions (len(ids), C, ph, pw) of the tiles ``ids`` of one rank -> its flat run ([C][h][w] per tile)."""
+    C = predictions.shape[1] if len(ids) else 1
+    flat = np.zeros(run_elems, dtype=np.float32)
+    for k, i in enumerate(ids):
+        _, _, rs, re = plan.valid_region(i)
+        reg = predictions[k][:, rs[1]:re[1], rs[2]:re[2]]
+        flat[off[i] * C:off[i] * C + reg.size] = reg.reshape(-1)
+    return flat
+
+
+def paste_packed(flat_all, plan, off, C):
+    """flat_all (world, run_elems) -> canvas (N,H,W,C)."""
+    world = flat_all.shape[0]
+    out = np.zeros(list(plan.data_shape) + [C], dtype=np.float32)
+    for i in range(plan.total()):
+        vgs, vge, _, _ = plan.valid_region(i)
+        h, w = int(vge[1] - vgs[1]), int(vge[2] - vgs[2])
+        reg = flat_all[i % world, off[i] * C:off[i] * C + C * h * w].reshape(C, h, w)
+        out[vgs[0], vgs[1]:vge[1], vgs[2]:vge[2], :] = np.moveaxis(reg, 0, -1)
+    return out

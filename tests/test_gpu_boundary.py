@@ -335,6 +335,23 @@ def test_packed_weight_cache(tmp_path):
     torch.save({k: v.cpu() for k, v in sd2.items()}, tmp_path / "I10_E1_gen.pth")
     c, hit_c = load()
     assert hit_c is False and not torch.equal(a, c)
+    # a damaged payload of the right size is refused (SHA-256 of the payload in the header) and rewritten
+    pk = tmp_path / "I10_E1_gen.unet0.f32.dsxpack"
+    raw = bytearray(pk.read_bytes())
+    raw[-5] ^= 0xFF
+    pk.write_bytes(bytes(raw))
+    d, hit_d = load()
+    assert hit_d is False and torch.equal(c, d)
+    # weights edited in place after load_network: the cached image no longer describes the module and is not used
+    o = _opt(_tiny_indi_section())
+    o["path"]["resume_state"] = str(tmp_path / "I10_E1")
+    m = create_model(o)
+    m.netG.e = 0.0
+    unet = [u for u in m.netG.modules() if isinstance(u, EngineUNet)][0]
+    with torch.no_grad():
+        next(iter(unet.parameters())).add_(0.05)
+    e = m.netG.inference(x, num_timesteps=2)
+    assert unet.pack_cache_hit is not True and not torch.equal(e, d)
 
 
 def _numpy_item(ch0, ch1, loc, p, nd, w, from_norm_target):
@@ -354,7 +371,10 @@ def _numpy_item(ch0, ch1, loc, p, nd, w, from_norm_target):
 
 def test_device_split_dataset_matches_numpy_restatement():
     """N2: frames resident on the GPU; normalisation statistics (compute_normalization_dict :29-74: quantiles) on the
-    device equal numpy's; batches of normalised tiles from one HIP launch are bit-exact with __getitem__'s arithmetic."""
+    device equal numpy's; batches of normalised tiles from one HIP launch are bit-exact with __getitem__'s arithmetic.
+    PARITY UNPINNED: data/split_dataset.py cannot be imported here (albumentations, skimage), so the comparison is
+    with a numpy restatement of its arithmetic written in this file (`_numpy_item`), not with the reference itself;
+    the reference's only fixture for this path (tests/test_tiling_setup.py) is the next test."""
     from diffsplitting_amd.data.split_dataset import (DataLocation, SplitDataset, SplitDatasetTiledPred,
                                                       compute_normalization_dict)
     rng = np.random.default_rng(11)
@@ -392,6 +412,15 @@ def test_device_split_dataset_matches_numpy_restatement():
     ref = _numpy_item(c0, c1, dt.patch_location(5), 64, dt.get_normalization_dict(), [1, 1], False)
     got = dt.tiles([5])
     assert np.array_equal(got["target"][0].cpu().numpy(), ref["target"]) and np.array_equal(got["input"][0].cpu().numpy(), ref["input"])
+    # a shard (arithmetic id sequence) goes through the plan's device tables, an arbitrary list through a per-call
+    # upload: same tiles; the whole-frame ground truth equals the stitched target tiles
+    shard = list(range(1, len(dt), 4))
+    by_seq = dt.tiles(shard)
+    by_loc = dt.tiles_at([dt.patch_location(i) for i in shard])
+    assert torch.equal(by_seq["input"], by_loc["input"]) and torch.equal(by_seq["target"], by_loc["target"])
+    gt = dt.normalized_target_frames()
+    assert gt.shape == (3, 128, 128, 2)
+    assert torch.equal(gt, dt.plan.stitch(dt.tiles(range(len(dt)))["target"]))
 
 
 def test_reference_known_answer_through_the_device_dataset():

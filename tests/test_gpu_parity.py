@@ -399,3 +399,57 @@ def test_stitch_known_answer_on_device(dev):
     tiles = torch.stack([plan.gather(torch.from_numpy(np.ascontiguousarray(data[..., c])).to(dev))
                          for c in range(C)], dim=1)
     assert np.array_equal(plan.stitch(tiles).cpu().numpy(), data)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("name,data_shape,grid_shape,patch_shape", [c for c in cases.TILE_CASES if c[0] != "hagen_490"])
+def test_cropped_exchange_kernels(name, data_shape, grid_shape, patch_shape, world, dev):
+    """The multi-rank exchange of CROPPED tiles (tile_stitcher.py:38-56 before the collective), every rank's
+    part played on the one GPU: pack each shard's valid regions batch by batch (device tables indexed by tile id), lay
+    the runs side by side as the all-gather would, paste from the packed layout -> bit-exact equal to the one-rank
+    stitch and to the oracle; the fused RangeInvariantPsnr sums equal the whole-tile path's."""
+    from diffsplitting_amd.data.tiling import TilePlan
+    plan = TilePlan(data_shape, grid_shape, patch_shape)
+    oplan = tiling.TilePlan(data_shape, grid_shape, patch_shape)
+    C = 2
+    rng = np.random.default_rng(7)
+    pred = rng.standard_normal((plan.total, C, patch_shape[1], patch_shape[2])).astype(np.float32)
+    gt = rng.standard_normal(tuple(data_shape) + (C,)).astype(np.float32)
+    pred_d, gt_d = torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev)
+    off, runs = plan.pack_layout(world)
+    ooff, oruns = tiling.pack_layout(oplan, world)
+    assert np.array_equal(off, ooff) and np.array_equal(runs, oruns)
+    stride = plan.rank_stride(world, C)
+    full = torch.zeros((world, max(stride, 1)), dtype=torch.float32, device=dev)
+    for r in range(world):
+        ids = list(range(r, plan.total, world))
+        for i in range(0, len(ids), 3):                                # batches of 3 tiles into the same run
+            chunk = ids[i:i + 3]
+            plan.pack(pred_d[chunk], world, chunk[0], full[r])
+        ref_run = tiling.pack_rank(pred[ids], ids, oplan, off, max(stride, 1))
+        assert np.array_equal(full[r].cpu().numpy(), ref_run)
+    canvas, ps = plan.paste_packed(full, C, world, gt=gt_d)
+    whole, ps_whole = plan.stitch_with_psnr(pred_d, gt_d)
+    assert torch.equal(canvas, whole) and torch.equal(ps, ps_whole)
+    assert np.array_equal(canvas.cpu().numpy(), tiling.stitch(pred, oplan))
+    assert torch.equal(plan.paste_packed(full, C, world), whole)
+
+
+def test_tile_id_lists_that_are_not_sequences(dev):
+    """Arbitrary id lists take the per-call upload forms (dsx_tiles_gather / dsx_stitch), sequences the plan's device
+    tables: same bytes either way."""
+    from diffsplitting_amd.data.tiling import TilePlan, as_sequence
+    plan = TilePlan((2, 96, 128), (1, 32, 32), (1, 64, 64))
+    frames = torch.randn(2, 96, 128, device=dev)
+    every = plan.gather(frames)
+    ids = [5, 0, 7, 3]
+    assert as_sequence(ids) is None and as_sequence([1, 4, 7]) == (1, 3, 3) and as_sequence([]) == (0, 1, 0)
+    assert torch.equal(plan.gather(frames, ids), every[ids])
+    assert torch.equal(plan.gather(frames, [1, 4, 7]), every[[1, 4, 7]])
+    tiles = every.unsqueeze(1).contiguous()
+    a = plan.stitch(tiles[ids], ids)
+    b = plan.stitch(tiles[[0, 3, 5, 7]], [0, 3, 5, 7])
+    assert torch.equal(a, b)
+    c = plan.stitch(tiles[[1, 4, 7]], [1, 4, 7], canvas=plan.stitch(tiles[[0, 3, 6]], [0, 3, 6]))
+    d = plan.stitch(tiles[[0, 1, 3, 4, 6, 7]], [0, 1, 3, 4, 6, 7])
+    assert torch.equal(c, d)

@@ -200,3 +200,39 @@ def test_config_loader_strips_comments(tmp_path):
     p.write_text('{\n "a": 1, // trailing comment\n "b": {"c": [1, 2]} // another\n}\n')
     opt = dict_to_nonedict(load_json(str(p)))
     assert opt["a"] == 1 and opt["b"]["c"] == [1, 2] and opt["missing"] is None and opt["b"]["zzz"] is None
+
+
+def test_reference_module_paths_via_compat(tmp_path):
+    """with diffsplitting_amd/compat on PYTHONPATH the reference's own import lines
+    (`import model as Model`, `import model.networks`, `from data.tiling_manager import ...`, split.py:1-20) resolve to
+    the engine-backed packages, from a working directory outside the repo, and define_G builds from a
+    reference-schema opt."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, sys
+import model as Model
+import model.networks, model.model, data.tiling_manager, data.tile_stitcher, data.split_dataset_tiledpred
+import core.logger as Logger, core.psnr
+from model.ddpm_modules.indi import InDI
+from model.ddpm_modules.joint_indi import JointIndi
+from model.sr3_modules.unet import UNet
+from model.sr3_modules.diffusion import GaussianDiffusion
+from data.tiling_manager import TileIndexManager, TilingMode
+import diffsplitting_amd.model.networks as real
+assert model.networks is real and Model.create_model is not None
+blob = json.load(open(sys.argv[1]))
+for name in ("splitting_cifar10_indi", "sr_sr3_16_128", "splitting_hagen_indi_joint"):
+    opt = Logger.dict_to_nonedict({"model": blob["model"][name], "phase": "val", "gpu_ids": None, "distributed": False})
+    netG = model.networks.define_G(opt)
+    assert [k for k in netG.state_dict()] == [k for k, _ in blob["keys"][name]], name
+mng = TileIndexManager((5, 512, 512), (1, 128, 128), (1, 256, 256), TilingMode.ShiftBoundary)
+assert mng.total_grid_count() == 45
+print("compat ok")
+"""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "diffsplitting_amd", "compat"), root])
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(GOLDEN, "state_dict_keys.json")], cwd=str(tmp_path),
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "compat ok" in r.stdout, r.stderr[-2000:]

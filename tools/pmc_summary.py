@@ -1,4 +1,4 @@
-"""Per-kernel summary of the three rocprofv3 --pmc passes of tools/measure_r02.sh (eager bench.py steps; the same
+"""Per-kernel summary of the three rocprofv3 --pmc passes of tools/measure_r03.sh (eager bench.py steps; the same
 program gives the same dispatch order in every pass, so dispatches are joined by ordinal among the conv kernels).
 
     python tools/pmc_summary.py <pmc_mfma dir> <pmc_fetch dir> <pmc_write dir> <ops.json> <out counters.json>
@@ -55,11 +55,13 @@ for k, g in sorted(agg.items(), key=lambda kv: -kv[1]["dur"]):
     print(f"{k[0]:58s} {k[1]:5d} {k[2]:7d} {n:3d} {dur / 1e3:7.1f} {busy:9.1f} {g['hbm'] / g['dur']:9.0f} {g['hbm'] / n / 1e6:9.1f} "
           f"{g['algo_mb'] / n:7.1f} {g['gflop'] / g['dur'] * 1e3 if g['dur'] else 0:6.0f}  {k[3]}")
 n = tot["n"]
-out = {"conv_launches_profiled": n, "hbm_bytes_per_conv_launch": tot["hbm"] / n,
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import bench as _bench
+out = {"kernel_source_sha": _bench.kernel_source_sha(), "conv_launches_profiled": n, "hbm_bytes_per_conv_launch": tot["hbm"] / n,
        "mfma_busy_frac_conv": tot["mfma"] / (1024.0 * tot["cyc"]) if tot["cyc"] else None,
        "hbm_gbps_conv": tot["hbm"] / tot["dur"], "avg_conv_launch_us_profiled": tot["dur"] / n / 1e3,
        "algorithmic_bytes_per_conv_launch": tot["algo_mb"] * 1e6 / n if tot["algo_mb"] else None,
-       "_note": "rocprofv3 --pmc passes over eager bench.py steps (tools/measure_r02.sh): SQ_VALU_MFMA_BUSY_CYCLES / (1024 x "
+       "_note": "rocprofv3 --pmc passes over eager bench.py steps (tools/measure_r03.sh): SQ_VALU_MFMA_BUSY_CYCLES / (1024 x "
                 "GRBM_GUI_ACTIVE / 8); HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of "
                 "MI355X_MICROARCH.md); separate passes"}
 print(json.dumps(out, indent=1))
