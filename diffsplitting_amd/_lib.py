@@ -69,6 +69,8 @@ SIGNATURES = {
     "dsx_time_predictor_set_mask": (_i, [_vp, _vp, _vp]),
     "dsx_time_predictor_forward": (_i, [_vp, _vp, _vp, _vp]),
     "dsx_sample_loop": (_i, [_vp, C.POINTER(StepTable), _vp, _vp, _vp, _u64, _pi32, _i, _vp, _i, _vp]),
+    "dsx_sr3_step": (_i, [_vp, _f, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _u64, _vp]),
+    "dsx_indi_step": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _u64, _vp]),
     "dsx_randn": (_i, [_vp, _i64, _u64, _u64, _vp]),
     "dsx_tile_plan": (_i64, [_pi64, _pi64, _pi64, _i, _pi64, _pi64, _i64]),
     "dsx_tile_regions": (_i, [_pi64, _pi64, _pi64, _i, _pi32, _i64]),
@@ -80,6 +82,7 @@ SIGNATURES = {
     "dsx_tileplan_create": (_i, [_pi64, _pi64, _pi64, _i, C.POINTER(_vp)]),
     "dsx_tileplan_destroy": (None, [_vp]),
     "dsx_tileplan_total": (_i64, [_vp]),
+    "dsx_tileplan_regions": (_i, [_vp, _pi32, _i64]),
     "dsx_tileplan_gather": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dsx_tileplan_gather_norm": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _f, _f, C.POINTER(C.c_double), _i, _vp, _vp, _vp]),
     "dsx_tileplan_stitch": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
@@ -95,7 +98,17 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():
-    _fn = getattr(lib, _name)
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        if "DSX_LIB_PATH" not in os.environ:
+            raise                      # the product library must export everything include/dsx.h declares
+        # a diagnostic variant (tools/build_variant.sh) built before an entry point was added: usable for timing
+        # experiments, the missing call fails loudly if it is ever made
+        def _missing(*_a, _n=_name, **_k):
+            raise DsxError(f"{LIB_PATH} (DSX_LIB_PATH variant) does not export {_n}: rebuild the variant")
+        setattr(lib, _name, _missing)
+        continue
     _fn.restype = _res
     _fn.argtypes = _args
 

@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs
   constexpr int SEGS = (DC * ES) / 16;                // 16-byte segments per K/Q unit row (16)
   static_assert(SEGS == 16, "a staged K/Q row is 256 bytes");
   const int seg = tid & 15, rsub = tid >> 4;          // rsub: 0..15
-  constexpr int PD = 2;                               // staged units in flight (global -> registers)
+#ifndef DSX_ATTN_PD
+#define DSX_ATTN_PD 2
+#endif
+  constexpr int PD = (KUNITS + VUNITS) < DSX_ATTN_PD ? (KUNITS + VUNITS) : DSX_ATTN_PD;   // staged units in flight (global -> registers)
   uint4 pre[PD][10];                                  // 8 K (or V) pieces + 2 Q pieces each
 
   // Every load goes through one buffer descriptor over this image's L token rows (q, k and v are column ranges of
@@ -220,8 +223,10 @@ __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs
   const int ntiles = (a.L + BK - 1) / BK;
   constexpr int UPT = KUNITS + VUNITS;
   static_assert(UPT % PD == 0 && UPT >= PD, "the register slot of a unit is a compile-time constant");
-  issue_unit(0, 0, pre[0]);
-  issue_unit(0, 1, pre[1]);
+  attn_static_for<PD>([&](auto pc) __attribute__((always_inline)) {
+    constexpr int u0 = decltype(pc)::value;
+    issue_unit(0, u0, pre[u0]);
+  });
   for (int t = 0; t < ntiles; ++t) {
     const int key0 = t * BK;
 #pragma unroll

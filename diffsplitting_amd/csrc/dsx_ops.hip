@@ -143,8 +143,10 @@ hipError_t launch_gn_finalize(const GnFinArgs& a, hipStream_t st) {
 //         (unet.py:18-50,177-187)
 //   ddpm: TimeEmbedding -> Linear -> Swish -> Linear ; film_k = Linear_k(Swish(t))
 //         (ddpm unet.py:19-34,78-96,163-173)
-// grid = (B, splits); every workgroup recomputes the tiny MLP and then produces
-// its slice of the F stacked FiLM outputs.
+// grid = (distinct time values, splits): every workgroup recomputes the tiny MLP (all 256 threads: four per output of
+// the second layer) and then produces its slice of the F stacked FiLM outputs, one or two per thread.  When the whole
+// batch shares ONE time value (InDI: one scalar t, indi.py:65; the SR3 / DDPM loops: the same step for every image,
+// diffusion.py:153-154) the work is done once and the result written to all B rows of `film`.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_temb(const TembArgs a) {
   extern __shared__ float shf[];
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256) void k_temb(const TembArgs a) {
   float* enc = shf;            // [inner]
   float* h1 = shf + inner;     // [hid]
   float* te = h1 + hid;        // [inner]
+  const bool shared_t = gridDim.x == 1 && a.B > 1;     // one time value for every image
   const int b = blockIdx.x;
   float tv;
   if (a.time) tv = a.time[a.n_time == 1 ? 0 : b];
@@ -167,17 +170,34 @@ __global__ __launch_bounds__(256) void k_temb(const TembArgs a) {
   for (int o = threadIdx.x; o < hid; o += 256) {
     const float* w = a.w1 + (size_t)o * inner;
     float acc = 0.f;
-    for (int k = 0; k < inner; ++k) acc = fmaf(enc[k], w[k], acc);
+    for (int k = 0; k < inner; k += 4) {                 // inner is a multiple of 4 (dsx_model_create)
+      const float4 w4 = *(const float4*)(w + k);
+      acc = fmaf(enc[k], w4.x, acc); acc = fmaf(enc[k + 1], w4.y, acc);
+      acc = fmaf(enc[k + 2], w4.z, acc); acc = fmaf(enc[k + 3], w4.w, acc);
+    }
     acc += a.b1[o];
     h1[o] = acc / (1.0f + expf(-acc));
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < inner; o += 256) {
-    const float* w = a.w2 + (size_t)o * hid;
-    float acc = 0.f;
-    for (int k = 0; k < hid; ++k) acc = fmaf(h1[k], w[k], acc);
-    acc += a.b2[o];
-    te[o] = a.flavour == 1 ? acc / (1.0f + expf(-acc)) : acc;  // ddpm feeds Swish(t) to each block
+  {
+    // second layer: output o = four adjacent lanes, each over a quarter of the hidden units; fixed order
+    const int part = threadIdx.x & 3, q = hid >> 2;      // hid = 4 * inner: whole quarters of whole float4s
+    for (int o = threadIdx.x >> 2; o < inner; o += 64) {
+      const float* w = a.w2 + (size_t)o * hid + part * q;
+      const float* h = h1 + part * q;
+      float acc = 0.f;
+      for (int k = 0; k < q; k += 4) {
+        const float4 w4 = *(const float4*)(w + k);
+        acc = fmaf(h[k], w4.x, acc); acc = fmaf(h[k + 1], w4.y, acc);
+        acc = fmaf(h[k + 2], w4.z, acc); acc = fmaf(h[k + 3], w4.w, acc);
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (part == 0) {
+        acc += a.b2[o];
+        te[o] = a.flavour == 1 ? acc / (1.0f + expf(-acc)) : acc;  // ddpm feeds Swish(t) to each block
+      }
+    }
   }
   __syncthreads();
   const int per = (a.F + gridDim.y - 1) / gridDim.y;
@@ -185,16 +205,27 @@ __global__ __launch_bounds__(256) void k_temb(const TembArgs a) {
   for (int f = f0 + threadIdx.x; f < f1; f += 256) {
     const float* w = a.wf + (size_t)f * inner;
     float acc = 0.f;
-    for (int k = 0; k < inner; ++k) acc = fmaf(te[k], w[k], acc);
-    a.film[(size_t)b * a.F + f] = acc + a.bf[f];
+    for (int k = 0; k < inner; k += 4) {
+      const float4 w4 = *(const float4*)(w + k);
+      acc = fmaf(te[k], w4.x, acc); acc = fmaf(te[k + 1], w4.y, acc);
+      acc = fmaf(te[k + 2], w4.z, acc); acc = fmaf(te[k + 3], w4.w, acc);
+    }
+    acc += a.bf[f];
+    if (shared_t) { for (int bb = 0; bb < a.B; ++bb) a.film[(size_t)bb * a.F + f] = acc; }
+    else a.film[(size_t)b * a.F + f] = acc;
   }
 }
 
 hipError_t launch_temb(const TembArgs& a, hipStream_t st) {
   const size_t lds = (size_t)(6 * a.inner) * sizeof(float);
-  int splits = (a.F + 1023) / 1024;
+  // one time value for the whole batch: computed once (explicit times: n_time == 1; table mode: not per sample)
+  const bool shared_t = a.time ? a.n_time == 1 : a.per_sample == 0;
+  const int rows = shared_t ? 1 : a.B;
+  int splits = (a.F + 255) / 256;                        // about one FiLM output per thread ...
+  const int cap = rows >= 8 ? 8 : 64;                    // ... unless the batch already fills the chip
+  if (splits > cap) splits = cap;
   if (splits < 1) splits = 1;
-  hipLaunchKernelGGL(k_temb, dim3((unsigned)a.B, (unsigned)splits), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_temb, dim3((unsigned)rows, (unsigned)splits), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -967,16 +967,19 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   static const int fuse_stats = getenv("DSX_FUSE_STATS") ? atoi(getenv("DSX_FUSE_STATS")) : 1;
   static const int ws_enabled = getenv("DSX_WS") ? atoi(getenv("DSX_WS")) : 1;
   static const int ws_1x1_enabled = getenv("DSX_WS_1X1") ? atoi(getenv("DSX_WS_1X1")) : 1;
+  int tile = -1;
+  const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);   // (keyed on a.has_gn, never on pointers)
+  const bool use_ws = mfma_ok && a.cpg != 2 && ws_enabled && (ks != 1 || ws_1x1_enabled) && stride == 1 && a.stage_mode == 0 &&
+                      a.ksplit == 1 && conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
+  // (Tried and rejected in round 3, measured: the GroupNorm finalised by the consuming conv's own compute waves during
+  // their start-up wait -- 14 to 22 k_gn_finalize launches fewer, but every such conv started 3-7 us later, the same
+  // or more than the launch it replaced cost inside the captured graph: step +0.4 .. +1.1 %.  DESIGN.md section 4.)
   if (s.gn) {   // every other kernel takes the per-channel scale / shift a k_gn_finalize launch prepares
     float *sc = nullptr, *sh = nullptr;
     plan_gn(ex, *s.gn, s.x0, s.x1.C ? &s.x1 : nullptr, &sc, &sh);
     a.gn_scale = sc; a.gn_shift = sh;
   }
-  int tile = -1;
-  const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);
   ex->launches++;
-  const bool use_ws = mfma_ok && a.cpg != 2 && ws_enabled && (ks != 1 || ws_1x1_enabled) && stride == 1 && a.stage_mode == 0 &&
-                      a.ksplit == 1 && conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
   if (fuse_stats && s.want_stats && mfma_ok && (use_ws ? conv_ws_fuses_stats(tile) : conv_tile_fuses_stats(tile)) &&
       a.ksplit == 1 && a.tb_log2 == 0 &&
       (a.Cout & 15) == 0 &&
@@ -1646,6 +1649,23 @@ extern "C" int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab, const fl
   return DSX_OK;
 }
 
+// ---- single reverse steps: one-row step tables through dsx_sample_loop, no graph (nothing to replay)
+extern "C" int dsx_sr3_step(dsx_exec* ex, float noise_level, float sqrt_recip_ac, float sqrt_recipm1_ac, float coef1,
+                            float coef2, float sigma, int clip_denoised, const float* cond, float* x, const float* noise,
+                            uint64_t seed, void* stream) {
+  dsx_step_table t{};
+  t.n_steps = 1; t.tcond = &noise_level; t.a = &sqrt_recip_ac; t.b = &sqrt_recipm1_ac; t.c1 = &coef1; t.c2 = &coef2;
+  t.sigma = &sigma; t.predict_eps = 1; t.clip = clip_denoised ? 1 : 0; t.per_sample = 0;
+  return dsx_sample_loop(ex, &t, cond, x, noise, seed, nullptr, 0, nullptr, 0, stream);
+}
+extern "C" int dsx_indi_step(dsx_exec* ex, float t_cur, float c_x0, float c_xt, float noise_scale, float* x,
+                             const float* noise, uint64_t seed, void* stream) {
+  dsx_step_table t{};
+  t.n_steps = 1; t.tcond = &t_cur; t.c1 = &c_x0; t.c2 = &c_xt; t.sigma = &noise_scale;
+  t.predict_eps = 0; t.clip = 0; t.per_sample = 0;
+  return dsx_sample_loop(ex, &t, nullptr, x, noise, seed, nullptr, 0, nullptr, 0, stream);
+}
+
 extern "C" int dsx_randn(float* out, int64_t n, uint64_t seed, uint64_t subseq, void* stream) {
   if (!out || n < 0) return fail(DSX_ERR_INVALID, "bad argument");
   if (n == 0) return DSX_OK;
@@ -1948,6 +1968,23 @@ extern "C" int dsx_tileplan_create(const int64_t data_shape[3], const int64_t gr
     }
     rc = check_regions(p->regions.data(), p->total, data_shape, (int)patch_shape[1], (int)patch_shape[2]);
     if (rc) return rc;
+    // stitch_predictions pastes tile after tile (tile_stitcher.py:68-80): where two valid regions overlap -- the
+    // shifted last tile of a ragged extent re-covers a strip of the tile before it -- the LATER tile's pixels stay.
+    // The device pastes all tiles at once, so the earlier tile's region is clipped to what survives: every canvas
+    // pixel is then written exactly once, by the tile the sequential loop leaves there (and is packed only once).
+    const int64_t cy = p->t.dim_count(1), cx = p->t.dim_count(2);
+    for (int64_t i = 0; i < p->total; ++i) {
+      int32_t* r = p->regions.data() + i * 8;
+      const int64_t iy = (i / cx) % cy, ix = i % cx;
+      if (cy >= 2 && iy == cy - 2) {
+        const int32_t* last = p->regions.data() + (i + cx) * 8;          // same frame and column, last row of tiles
+        if (last[1] < r[1] + r[3]) r[3] = std::max(0, last[1] - r[1]);
+      }
+      if (cx >= 2 && ix == cx - 2) {
+        const int32_t* last = p->regions.data() + (i + 1) * 8;
+        if (last[2] < r[2] + r[4]) r[4] = std::max(0, last[2] - r[2]);
+      }
+    }
   }
   *out = p.release();
   return DSX_OK;
@@ -1959,6 +1996,13 @@ extern "C" void dsx_tileplan_destroy(dsx_tileplan* p) {
   delete p;
 }
 extern "C" int64_t dsx_tileplan_total(const dsx_tileplan* p) { return p ? p->total : 0; }
+// the paste regions the plan's device kernels use (dsx_tile_regions clipped where a later tile overwrites)
+extern "C" int dsx_tileplan_regions(const dsx_tileplan* p, int32_t* regions, int64_t capacity) {
+  if (!p || !regions) return fail(DSX_ERR_INVALID, "null argument");
+  if (capacity < p->total) return fail(DSX_ERR_INVALID, "capacity too small");
+  memcpy(regions, p->regions.data(), (size_t)p->total * 32);
+  return DSX_OK;
+}
 
 // host only: pixel offset of every tile inside its rank's packed run and the pixels of every rank's run
 extern "C" int dsx_tileplan_pack_layout(const dsx_tileplan* p, int world, int64_t* off, int64_t* rank_pixels) {

@@ -58,6 +58,16 @@ class TilePlan:
                                        self.total))
         self._h = None
         self._layouts = {}
+        # the regions every paste uses: the valid regions, clipped where a later tile overwrites (a ragged extent's
+        # shifted last tile), so that all tiles can be pasted at once with the sequential loop's result
+        self.valid_regions = self.regions
+        try:
+            clipped = np.zeros((self.total, 8), dtype=np.int32)
+            if self.total:
+                check(lib.dsx_tileplan_regions(self.handle, clipped.ctypes.data_as(C.POINTER(C.c_int32)), self.total))
+            self.regions = clipped
+        except DsxError:
+            pass                                     # tiling modes whose tiles leave the frames have no device plan
 
     # ---- the device-resident plan ------------------------------------------------------------------------
     @property

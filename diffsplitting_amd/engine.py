@@ -117,6 +117,10 @@ class UNetEngine:
                 raise DsxError(f"state dict lacks {key}")
             t = sd[key].detach().to("cpu", torch.float32).contiguous()
             if tuple(t.shape) != shp:
+                if "noise_func" in n and len(shp) >= 1 and t.shape[0] == 2 * shp[0] and tuple(t.shape[1:]) == tuple(shp[1:]):
+                    raise DsxError(f"{key}: {tuple(t.shape)} is a FeatureWiseAffine with use_affine_level=True "
+                                   f"((1 + gamma) x + beta, sr3 unet.py:34-50); the engine implements the additive form "
+                                   f"every reference config uses (use_affine_level=False), expected {shp}")
                 raise DsxError(f"{key}: shape {tuple(t.shape)} != {shp}")
             check(lib.dsx_model_set_param(self._h, i, C.c_void_p(t.data_ptr()), t.numel()))
         if self.flavour == "sr3" and self.cfg.with_time_emb:

@@ -258,6 +258,7 @@ class JointIndiSampler(_SamplerBase):
         self.scale_param = nn.Parameter(torch.tensor(1.0))
         self.w_input_loss = w_input_loss
         self._streams = None
+        self.concurrent = True        # the two loops on two HIP streams; False: back to back on the current stream
 
     @property
     def prediction_channels(self):
@@ -275,7 +276,7 @@ class JointIndiSampler(_SamplerBase):
     def inference(self, x_in, continuous=False, num_timesteps=None, t_float_start=0.5, eps=1e-8):
         for s in (self.indi1, self.indi2):
             s.noise_source, s.use_graph = self.noise_source, self.use_graph   # indi1's draws first (Q4)
-        if self.noise_source is not None:
+        if self.noise_source is not None or not self.concurrent:
             # host draws are order-dependent: finish indi1's before indi2's start
             ch1 = self.indi1.inference(x_in, continuous, num_timesteps, t_float_start, eps)
             ch2 = self.indi2.inference(x_in, continuous, num_timesteps, 1 - t_float_start, eps)

@@ -200,6 +200,20 @@ int dsx_sample_loop(dsx_exec* ex, const dsx_step_table* tab,
                     const int32_t* snap_steps, int n_snap, float* snap_nchw_dev,
                     int use_graph, void* stream);
 
+/* One reverse step on the state x (B, C, H, W) in place: dsx_sample_loop with a one-row table, eager.
+ *   dsx_sr3_step : p_sample of sr3 / ddpm (sr3 diffusion.py:141-175): the step's scalars as set_new_noise_schedule
+ *                  tabulates them -- noise_level = sqrt_alphas_cumprod_prev[t+1], sqrt_recip_alphas_cumprod[t],
+ *                  sqrt_recipm1_alphas_cumprod[t], posterior_mean_coef1/2[t], sigma = exp(0.5 posterior_log_variance
+ *                  _clipped[t]) (0 at t == 0: no draw)
+ *   dsx_indi_step: inference_one_step of InDI (indi.py:62-69): x <- c_x0 UNet(x, t) + c_xt x + noise_scale z with
+ *                  c_x0 = delta / t, c_xt = 1 - delta / t, noise_scale = e (t - delta)
+ * noise_dev: (1, B, C, H, W) injected draw or NULL -> Philox normals keyed by seed. */
+int dsx_sr3_step(dsx_exec* ex, float noise_level, float sqrt_recip_alphas_cumprod, float sqrt_recipm1_alphas_cumprod,
+                 float posterior_mean_coef1, float posterior_mean_coef2, float sigma, int clip_denoised,
+                 const float* cond_nchw_dev, float* x_nchw_dev, const float* noise_dev, uint64_t seed, void* stream);
+int dsx_indi_step(dsx_exec* ex, float t_cur, float c_x0, float c_xt, float noise_scale, float* x_nchw_dev,
+                  const float* noise_dev, uint64_t seed, void* stream);
+
 /* Fills n fp32 values with N(0,1) from the engine's Philox4x32-10 stream. */
 int dsx_randn(float* out_dev, int64_t n, uint64_t seed, uint64_t subsequence, void* stream);
 
@@ -272,6 +286,11 @@ int dsx_tileplan_create(const int64_t data_shape[3], const int64_t grid_shape[3]
                         int tiling_mode, dsx_tileplan** out);        /* host only; fails if a tile leaves the frames */
 void dsx_tileplan_destroy(dsx_tileplan* plan);
 int64_t dsx_tileplan_total(const dsx_tileplan* plan);
+/* The plan's paste regions, 8 int32 per tile as dsx_tile_regions: stitch_predictions pastes tile after tile
+ * (tile_stitcher.py:68-80), so where valid regions overlap (the shifted last tile of a ragged extent re-covers a strip
+ * of its neighbour) the later tile's pixels stay; the plan clips the earlier tile's region to what survives, so that
+ * all tiles can be pasted at once and every canvas pixel is written -- and exchanged -- exactly once. */
+int dsx_tileplan_regions(const dsx_tileplan* plan, int32_t* regions, int64_t capacity);
 /* dsx_tiles_gather / dsx_tiles_gather_norm for the tiles first + k*stride, k < count (<= 65535 per call) */
 int dsx_tileplan_gather(dsx_tileplan* plan, const float* frames_dev, int64_t first, int64_t stride, int64_t count,
                         float* tiles_dev, void* stream);

@@ -87,6 +87,23 @@ class TilePlan:
         return vgs, vge, rs, re
 
 
+def paste_region(plan, idx):
+    """The part of tile ``idx``'s valid region that survives stitch_predictions' sequential paste
+    (tile_stitcher.py:68-80: a later tile overwrites): the shifted last tile of a ragged extent re-covers a strip of
+    the tile before it along that dimension.  Returns (vgs, vge, rs, re) like valid_region."""
+    vgs, vge, rs, re = plan.valid_region(idx)
+    vge = vge.copy()
+    cy, cx = plan.dim_count(1), plan.dim_count(2)
+    iy, ix = (idx // cx) % cy, idx % cx
+    if cy >= 2 and iy == cy - 2:
+        nxt = plan.valid_region(idx + cx)[0]
+        vge[1] = max(vgs[1], min(vge[1], nxt[1]))
+    if cx >= 2 and ix == cx - 2:
+        nxt = plan.valid_region(idx + 1)[0]
+        vge[2] = max(vgs[2], min(vge[2], nxt[2]))
+    return vgs, vge, rs, rs + (vge - vgs)
+
+
 def stitch(predictions, plan):
     """tile_stitcher.py:10-81 for 3-D data (N,H,W): predictions (T,C,ph,pw) -> (N,H,W,C)."""
     out = np.zeros(list(plan.data_shape) + [predictions.shape[1]], dtype=predictions.dtype)
@@ -115,7 +132,7 @@ def pack_layout(plan, world):
     off = np.zeros(T, dtype=np.int64)
     runs = np.zeros(world, dtype=np.int64)
     for i in range(T):
-        vgs, vge, _, _ = plan.valid_region(i)
+        vgs, vge, _, _ = paste_region(plan, i)
         off[i] = runs[i % world]
         runs[i % world] += int(vge[1] - vgs[1]) * int(vge[2] - vgs[2])
     return off, runs
@@ -126,7 +143,7 @@ def pack_rank(predictions, ids, plan, off, run_elems):
     C = predictions.shape[1] if len(ids) else 1
     flat = np.zeros(run_elems, dtype=np.float32)
     for k, i in enumerate(ids):
-        _, _, rs, re = plan.valid_region(i)
+        _, _, rs, re = paste_region(plan, i)
         reg = predictions[k][:, rs[1]:re[1], rs[2]:re[2]]
         flat[off[i] * C:off[i] * C + reg.size] = reg.reshape(-1)
     return flat
@@ -137,7 +154,7 @@ def paste_packed(flat_all, plan, off, C):
     world = flat_all.shape[0]
     out = np.zeros(list(plan.data_shape) + [C], dtype=np.float32)
     for i in range(plan.total()):
-        vgs, vge, _, _ = plan.valid_region(i)
+        vgs, vge, _, _ = paste_region(plan, i)
         h, w = int(vge[1] - vgs[1]), int(vge[2] - vgs[2])
         reg = flat_all[i % world, off[i] * C:off[i] * C + C * h * w].reshape(C, h, w)
         out[vgs[0], vgs[1]:vge[1], vgs[2]:vge[2], :] = np.moveaxis(reg, 0, -1)

@@ -453,3 +453,47 @@ def test_tile_id_lists_that_are_not_sequences(dev):
     c = plan.stitch(tiles[[1, 4, 7]], [1, 4, 7], canvas=plan.stitch(tiles[[0, 3, 6]], [0, 3, 6]))
     d = plan.stitch(tiles[[0, 1, 3, 4, 6, 7]], [0, 1, 3, 4, 6, 7])
     assert torch.equal(c, d)
+
+
+def test_single_step_entry_points_equal_the_loop(dev):
+    """dsx_indi_step / dsx_sr3_step (one reverse step per call, indi.py:62-69, sr3 diffusion.py:141-175) step
+    through the same schedule as dsx_sample_loop with the same injected draws: bitwise the same final state."""
+    import ctypes as C
+    from diffsplitting_amd import _lib, engine
+    lib, check = _lib.lib, _lib.check
+    # InDI
+    sd, _ = golden_state_dict("loop_indi_n3_t1.0")
+    case = cases.UNET_CASES["ddpm_tiny"]
+    eng = build_engine(case["cfg"], "ddpm", sd)
+    n = 3
+    tab = engine.indi_step_table(n, 1.0)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(3, 2, 32, 48, generator=g).to(dev)
+    noise = torch.randn(n, 3, 2, 32, 48, generator=g).to(dev)
+    ref, _ = eng.sample_loop(tab, x0.clone(), noise=noise, use_graph=False)
+    ex = eng.executor(3, 32, 48)
+    x = x0.clone()
+    for s in range(n):
+        check(lib.dsx_indi_step(ex, float(tab.tcond[s]), float(tab.c1[s]), float(tab.c2[s]), float(tab.sigma[s]),
+                                C.c_void_p(x.data_ptr()), C.c_void_p(noise[s:s + 1].contiguous().data_ptr()), 0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    # SR3
+    sd, _ = golden_state_dict("loop_sr3_lin_8")
+    case = cases.UNET_CASES["sr3_tiny"]
+    eng = build_engine(case["cfg"], "sr3", sd)
+    bufs, gam = engine.gaussian_buffers(cases.SCHEDULES["lin_8"])
+    tab = engine.gaussian_step_table(bufs, gam, "sr3", clip_denoised=True)
+    T = tab.n_steps
+    cond = torch.randn(2, 3, 32, 32, generator=g).to(dev)
+    x0 = torch.randn(2, 3, 32, 32, generator=g).to(dev)
+    noise = torch.randn(T, 2, 3, 32, 32, generator=g).to(dev)
+    ref, _ = eng.sample_loop(tab, x0.clone(), cond=cond, noise=noise, use_graph=False)
+    ex = eng.executor(2, 32, 32, 3)
+    x = x0.clone()
+    for s in range(T):
+        check(lib.dsx_sr3_step(ex, float(tab.tcond[s]), float(tab.a[s]), float(tab.b[s]), float(tab.c1[s]), float(tab.c2[s]),
+                               float(tab.sigma[s]), 1, C.c_void_p(cond.data_ptr()), C.c_void_p(x.data_ptr()),
+                               C.c_void_p(noise[s:s + 1].contiguous().data_ptr()), 0, None))
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)

@@ -109,11 +109,21 @@ def test_tile_plan_equals_reference(name, data_shape, grid_shape, patch_shape):
     # regions against the oracle's restatement of tile_stitcher.py:26-56
     from oracle.tiling import TilePlan as OPlan
     op = OPlan(data_shape, grid_shape, patch_shape)
-    for i in range(0, plan.total, max(1, plan.total // 50)):
-        vgs, vge, rs, re = op.valid_region(i)
-        r = plan.regions[i]
-        assert (r[0], r[1], r[2]) == tuple(vgs) and (r[3], r[4]) == (vge[1] - vgs[1], vge[2] - vgs[2])
-        assert (r[5], r[6]) == (rs[1], rs[2])
+    from oracle.tiling import paste_region
+    covered = 0
+    for i in range(plan.total):
+        if i % max(1, plan.total // 50) == 0:
+            vgs, vge, rs, re = op.valid_region(i)
+            r = plan.valid_regions[i]
+            assert (r[0], r[1], r[2]) == tuple(vgs) and (r[3], r[4]) == (vge[1] - vgs[1], vge[2] - vgs[2])
+            assert (r[5], r[6]) == (rs[1], rs[2])
+            # the paste regions: clipped where the sequential paste of tile_stitcher.py:68-80 lets a later tile overwrite
+            vgs, vge, rs, re = paste_region(op, i)
+            r = plan.regions[i]
+            assert (r[0], r[1], r[2]) == tuple(vgs) and (r[3], r[4]) == (vge[1] - vgs[1], vge[2] - vgs[2])
+            assert (r[5], r[6]) == (rs[1], rs[2])
+        covered += int(plan.regions[i][3]) * int(plan.regions[i][4])
+    assert covered == int(np.prod(data_shape))                        # every canvas pixel is pasted exactly once
 
 
 def test_tile_plan_rejects_bad_shapes():
@@ -236,3 +246,17 @@ print("compat ok")
     r = subprocess.run([sys.executable, "-c", code, os.path.join(GOLDEN, "state_dict_keys.json")], cwd=str(tmp_path),
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "compat ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_affine_film_checkpoint_is_rejected_by_name():
+    """use_affine_level=True (sr3 unet.py:34-50: Linear to 2 C rows, (1 + gamma) x + beta) is not implemented -- no
+    reference config enables it; such a checkpoint must be refused with a message that says so, not a bare shape error."""
+    from diffsplitting_amd._lib import DsxError
+    from oracle.weights import synth_state_dict
+    g = load_golden("unet_sr3_tiny")
+    eng = _engine_for(cases.UNET_CASES["sr3_tiny"]["cfg"], "sr3")
+    sd = synth_state_dict(g["keys"], 0)
+    k = next(k for k in sd if "noise_func" in k and k.endswith("weight"))
+    sd[k] = torch.cat([sd[k], sd[k]], dim=0)
+    with pytest.raises(DsxError, match="use_affine_level"):
+        eng.load_state_dict(sd)

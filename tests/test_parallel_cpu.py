@@ -68,10 +68,10 @@ def _exchange_worker(rank, world, port, case, q):
     ok = ok and tuple(full.shape) == (world, stride)
     canvas = tiling.paste_packed(full.numpy(), oplan, off, C)
     ok = ok and np.array_equal(canvas, tiling.stitch(pred, oplan))    # bit-exact vs the one-rank stitch
-    # the collective moves the valid regions (the canvas; a ragged extent's shifted last tile re-covers a strip) plus
-    # the padding to equal runs
+    # the collective moves the canvas (every pixel exactly once: overlapping valid regions are clipped to what the
+    # sequential paste leaves) plus the padding to equal runs
     valid = int(runs.sum()) * C * 4
-    ok = ok and valid >= int(np.prod(data_shape)) * C * 4
+    ok = ok and valid == int(np.prod(data_shape)) * C * 4
     gathered = world * stride * 4
     padding = int((runs.max() * world - runs.sum()) * C * 4)
     whole_tiles = world * ((plan.total + world - 1) // world) * C * patch_shape[1] * patch_shape[2] * 4
