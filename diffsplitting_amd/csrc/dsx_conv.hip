@@ -31,7 +31,7 @@
 #include <utility>
 
 #ifndef DSX_WS_DEPTH_EXPR
-#define DSX_WS_DEPTH_EXPR (bm == 64 ? 5 : (bm == 256 ? 3 : (ks == 1 ? 3 : 4)))   // measured: one more group in flight than the HBM latency strictly needs
+#define DSX_WS_DEPTH_EXPR (bm == 64 ? 5 : (bm == 256 ? 2 : (ks == 1 ? 3 : 4)))   // measured: one more group in flight than the HBM latency strictly needs (256-pixel tile: 2, its third MFMA image takes the LDS of the fourth ring slot)
 #endif
 // residual prefetch one tile ahead: only with one N block per wave.  With two, the register demand passes 256 and
 // hipcc (ROCm 7.2) fails in its spill path ("Illegal instruction detected: Operand has incorrect register class
@@ -58,6 +58,9 @@
 #endif
 #ifndef DSX_LOADER_PRIO
 #define DSX_LOADER_PRIO 1
+#endif
+#ifndef DSX_LOADER_PRIO_EXPR
+#define DSX_LOADER_PRIO_EXPR DSX_LOADER_PRIO   // (may name MB, KS, NB: per-tile experiments)
 #endif
 #ifndef DSX_RING_DEPTH
 #define DSX_RING_DEPTH 6  // weight-fragment prefetch ring depth for 3x3 (divides 18)
@@ -307,6 +310,36 @@ __device__ __forceinline__ f32x16 mfma_step(const uint4 w, const f32x4_t px, f32
   }
 }
 
+// Loader -> compute hand-off of k_conv_ws.  NBUF == 2: two MFMA images, one workgroup barrier per (tile, group) item
+// (strict alternation).  NBUF == 3 / 4: three / four images and LDS counters instead of the barrier -- FULL (one per
+// loader wave: items converted) and FREE (one per compute wave: items consumed): the loaders may run two items
+// ahead, i.e. they convert during the compute waves' epilogue instead of parking at the barrier, and the compute waves
+// find the next tile's first groups ready.  Spins are bounded (a lost hand-off gives wrong pixels, never a hung GPU).
+// Measured (round 3, A/B inside one gpurun call, three alternations): counters for the 256-pixel 3 x 3 tile only (the
+// 64-channel layers of the 128^2 level: two groups per tile, so the loaders used to idle through every epilogue and
+// the compute waves then waited 3500 cycles for the second group) -0.9 % on the step, those layers -10 %; for every
+// 3 x 3 tile -0.5 % (deep-K layers lose 2 us each to the polling); four buffers no better than three.
+#ifndef DSX_WS_NBUF_EXPR
+#define DSX_WS_NBUF_EXPR(bm, ks, nb) ((bm) == 256 && (ks) == 3 ? 3 : 2)
+#endif
+static constexpr int ws_nbuf(int bm, int ks, int nb) { return DSX_WS_NBUF_EXPR(bm, ks, nb); }
+// a counter PER WAVE (four words, read with one ds_read_b128): a single shared counter would let three fast waves
+// stand in for a slow one, and the image of the item that one is still reading would be overwritten
+static __device__ __forceinline__ void lds_wait_all_ge(unsigned addr, int target) {
+  for (int spin = 0; spin < (1 << 18); ++spin) {   // ~30 ms: a hand-off normally takes microseconds
+    f32x4_t v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    const int4 c = __builtin_bit_cast(int4, v);
+    const int m = min(min(c.x, c.y), min(c.z, c.w));
+    if (__builtin_amdgcn_readfirstlane(m) >= target) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+static __device__ __forceinline__ void lds_signal(unsigned addr, int wave, int count) {   // this wave's word := count, behind its own LDS traffic
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(addr + 4u * (unsigned)wave), "v"(count) : "memory");
+}
+
 // MB   : 32-row M blocks per wave;  WM x WN waves (WM*WN == 4); every wave owns ONE
 //        32-channel N block, so with WM == 1 no weight fragment is loaded twice.
 // CPG  : channel chunks staged per barrier ("group"); 1 for 3x3, 2 for 1x1 (few steps per chunk)
@@ -318,7 +351,8 @@ __device__ __forceinline__ f32x16 mfma_step(const uint4 w, const f32x4_t px, f32
 // code has no predicates.  LDS image: pixel stride PIXB, row pitch `a.lds_row` chosen by the
 // host so that ds_read_b128 of a 32-row fragment is bank-conflict-free (see conv_lds_row).
 template <typename DT, int MB, int WM, int WN, int KS, int S, int CPG, int D, int MAX_IT>
-__global__ __launch_bounds__(256, (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (MB == 4 ? 2 : 1)))) void k_conv_mfma(const ConvArgs a) {
+__global__ __launch_bounds__(256, ((KS == 3 && CPG == 2) ? 2   // two-chunk 3 x 3 variant: up to 11 staging units per thread in flight (spills at 168 VGPRs)
+                                  : (MB == 1 ? (S == 2 ? 3 : 4) : (MB == 2 ? 3 : (MB == 4 ? 2 : 1))))) void k_conv_mfma(const ConvArgs a) {
   constexpr int KC = Chunk<DT>::KC;
   constexpr int CPU = Unit<DT>::N;            // channels per 16-byte staging unit
   constexpr int ES = (int)sizeof(DT);         // bytes per activation element in HBM
@@ -773,12 +807,15 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   const int PP = PPI << a.tb_log2;
   const int RB = a.lds_row;
   const int BUFB = (PH << a.tb_log2) * RB;
-  // [image 0][image 1][GroupNorm scale/shift of three tiles' images][raw ring]
+  // [image 0 .. NBUF-1][GroupNorm scale/shift of three tiles' images][raw ring][FULL, FREE counters]
+  constexpr int NBUF = ws_nbuf(32 * MB * WM, KS, NB);
+  static_assert(NBUF >= 2 && NBUF <= 4, "two images and a barrier, or three / four and counters");
   const int C = a.C0 + a.C1;
   const int AFFB = a.has_gn ? ((2 * C * 4 + 15) & ~15) : 0;     // bytes of one tile's {scale[C], shift[C]}
-  float* const aff_base = (float*)(lds + 2 * BUFB);
-  unsigned char* const raw_base = lds + 2 * BUFB + 3 * AFFB;
+  float* const aff_base = (float*)(lds + NBUF * BUFB);
+  unsigned char* const raw_base = lds + NBUF * BUFB + 3 * AFFB;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;  // LDS byte address of lds[0]
+  const unsigned full_addr = lds0 + NBUF * BUFB + 3 * AFFB + NSLOT * RAWB;   // FULL[4 loader waves], FREE[4 compute waves] at +16 (NBUF == 3)
   const int G = a.kchunks / CPG;                // channel groups per tile (no split-K here; host: G >= 2, TB == 1)
 
   // persistent work list: this workgroup owns N tile `nt` and M tiles p, p+wpn, ...
@@ -816,7 +853,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     // The loader waves are dispatched after the compute waves, and vector issue on a SIMD is arbitrated by
     // priority, then age: as the younger wave their GroupNorm/Swish VALU stream only gets the slots the MFMA
     // wave leaves over, and they become the critical path.  Static priority for the whole kernel.
-    __builtin_amdgcn_s_setprio(DSX_LOADER_PRIO);
+    __builtin_amdgcn_s_setprio(DSX_LOADER_PRIO_EXPR);
     // Per-thread, tile-invariant description of its NIT units: LDS image offset, source pixel offset
     // relative to the tile's origin pixel, and which patch borders the unit lies on.  Per tile only the
     // origin offset and four "tile touches the image border" flags change (no divisions, no per-unit
@@ -881,7 +918,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     TilePos posC = posI;                                                         // tile being consumed
     int baseI = tile_base(posI), flagsI = tile_flags(posI), flagsC = flagsI;
     int gI = 0;               // group of the next item to issue
-    [[maybe_unused]] int tiC = 0;   // tile of the next item to consume (diagnostic stamps only)
+    int tiC = 0;              // tile of the next item to consume
     int gC = 0;               // its group
     int affslot = 0;          // tiC % 3: LDS slot of that tile's scale/shift
 
@@ -920,9 +957,15 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       cF = gC * (CPG * KC) + cvg * CPU;
       flagsF = flagsC;
       gnF = a.gn_scale != nullptr && cF < C;
-      const unsigned src = lds0 + 2 * BUFB + 3 * AFFB + slot * RAWB + ltid * 16;
+      if constexpr (NBUF >= 3) {
+        // the scale/shift slot of tile t (t >= 3) is written by the compute waves' epilogue of tile t - 3, which is
+        // over once they have consumed the first item of tile t - 2 (with the per-item barrier of NBUF == 2 the
+        // three-tile lead alone guarantees this; running ahead, the loaders ask)
+        if (gnF && gC == 0 && tiC >= 3) lds_wait_all_ge(full_addr + 16, (tiC - 2) * G + 1);
+      }
+      const unsigned src = lds0 + NBUF * BUFB + 3 * AFFB + slot * RAWB + ltid * 16;
       if (gnF) {
-        const unsigned af = lds0 + 2 * BUFB + affslot * AFFB;   // slot tiC % 3
+        const unsigned af = lds0 + NBUF * BUFB + affslot * AFFB;   // slot tiC % 3
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
           asm volatile("ds_read_b128 %0, %1" : "=v"(av[q]) : "v"(af + (cF + 4 * q) * 4) : "memory");
@@ -1027,25 +1070,37 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     DSX_STAMP_T(112, tid == 256);       // item 0 has landed
     fetch_next();                       // item 0
     convert(0);
+    if constexpr (NBUF >= 3) { if (total > 0) lds_signal(full_addr, wave, 1); }   // item 0 is ready
     DSX_STAMP_T(113, tid == 256);       // item 0 converted
     if (total > 1) {
       wait_young(min(P - 1, total - 2));
       fetch_next();                     // item 1
     }
-    ws_barrier();                       // image of item 0 is ready
+    if constexpr (NBUF == 2) ws_barrier();   // image of item 0 is ready
     DSX_STAMP_T(64, tid == 256);
+    int bufL = 1;                       // image buffer of item v + 1
     for (int v = 0; v < total; ++v) {
       // the slot of item v was copied to registers two iterations ago: reuse it for item v+NSLOT
       if (issued < total) issue_next();
       DSX_STAMP_T(65 + 4 * v, tid == 256 && v < 9);
-      if (v + 1 < total) convert((v + 1) & 1);
+      if (v + 1 < total) {
+        if constexpr (NBUF >= 3) {
+          // buffer (v + 1) % NBUF held item v + 1 - NBUF: every compute wave must have released it (v + 2 - NBUF items consumed)
+          if (v + 1 >= NBUF) lds_wait_all_ge(full_addr + 16, v + 2 - NBUF);
+          convert(bufL);
+          lds_signal(full_addr, wave, v + 2);     // items 0 .. v + 1 are ready
+        } else {
+          convert((v + 1) & 1);
+        }
+      }
+      if (++bufL == NBUF) bufL = 0;
       DSX_STAMP_T(66 + 4 * v, tid == 256 && v < 9);
       if (v + 2 < total) {
         wait_young(min(P - 1, total - 3 - v));
         fetch_next();                   // item v+2
       }
       DSX_STAMP_T(67 + 4 * v, tid == 256 && v < 9);
-      ws_barrier();
+      if constexpr (NBUF == 2) ws_barrier();
       DSX_STAMP_T(68 + 4 * v, tid == 256 && v < 9);
     }
     return;
@@ -1228,10 +1283,14 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
     }
   }
 
-  ws_barrier();   // scale/shift visible to the loaders
-  ws_barrier();   // image of item 0 is ready
+  if constexpr (NBUF >= 3) {
+    if (tid < 8) ((unsigned*)(lds + NBUF * BUFB + 3 * AFFB + NSLOT * RAWB))[tid] = 0u;   // FULL[4], FREE[4]
+  }
+  ws_barrier();   // scale/shift (and the zeroed counters) visible to the loaders
+  if constexpr (NBUF == 2) ws_barrier();   // image of item 0 is ready
   DSX_STAMP_T(0, tid == 0);
   int g = 0, ti = 0, aslot = 0;   // aslot == ti % 3
+  int ibuf = 0;                   // image buffer of the current item (v % NBUF)
   constexpr int PF = NB == 2 ? 1 : DSX_PF;         // operand fragments are read PF steps ahead of their MFMAs (a step is NB x longer)
   static_assert(PF < NSTEP && PF * MB <= 15, "lgkmcnt is 4 bits");
   // The ring slot of step s of item v is (v * NSTEP + s) % D: static for D <= NSTEP; for a ring of RP groups the item
@@ -1779,6 +1838,7 @@ static constexpr TileCfg kTiles[TILE_COUNT] = {
     {1, 2, 2},  // 64 x 64
     {1, 4, 1},  // 128 x 32: layers with <= 32 output channels (the final conv, 16-channel Hagen levels): all four
                 // waves along M, no wave multiplies padding columns
+    {2, 4, 1},  // 256 x 32: the same with a 16 x 16 pixel tile (two-chunk variant only, see conv_g2_lds_bytes)
 };
 
 ConvTileInfo conv_tile_info(int tile) {
@@ -1838,29 +1898,41 @@ int conv_lds_row_g2(int tw_log2) {
   else if (tw_log2 == 3) { rb = (rb + 127) & ~127; if (((rb >> 7) & 1) == 0) rb += 128; }
   return rb;
 }
+// patch pixels the two-chunk variant's staging registers are sized for, per tile
+static constexpr int g2_max_px(int tile) { return tile == TILE_256x32 ? 324 : 220; }
 size_t conv_g2_lds_bytes(int tile, const ConvArgs& a) {
-  if (tile != TILE_128x64) return 0;
+  if (tile != TILE_128x64 && tile != TILE_256x32 && tile != TILE_128x32) return 0;
   const ConvTileInfo ti = conv_tile_info(tile);
   if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != ti.BM || a.tb_log2 != 0) return 0;
-  if (patch_pixels(3, 1, a) > 220 || a.lds_row != conv_lds_row_g2(a.tw_log2)) return 0;
+  if (patch_pixels(3, 1, a) > g2_max_px(tile) || a.lds_row != conv_lds_row_g2(a.tw_log2)) return 0;
   if (a.kchunks % 2 || a.stage_mode != 0) return 0;
   const int ph = ((1 << a.th_log2) - 1) + 3;
   const size_t bufb = (size_t)ph * a.lds_row;
   const size_t need = (a.kchunks / 2 > 1 ? 2 : 1) * bufb;     // a single group never touches the second buffer
-  return need <= 64 * 1024 ? need : 0;
+  return need <= 160 * 1024 ? need : 0;
 }
-template <typename DT> static hipError_t launch_g2(const ConvArgs* ap, size_t lds, hipStream_t st) {
-  constexpr TileCfg t = kTiles[TILE_128x64];
-  auto kern = k_conv_mfma<DT, t.MB, t.WM, t.WN, 3, 1, 2, 6, (220 * 8 + 255) / 256>;
-  if (!ap) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+template <typename DT, int TILE> static hipError_t launch_g2_tile(const ConvArgs* ap, size_t lds, hipStream_t st) {
+  constexpr TileCfg t = kTiles[TILE];
+  auto kern = k_conv_mfma<DT, t.MB, t.WM, t.WN, 3, 1, 2, 6, (g2_max_px(TILE) * 8 + 255) / 256>;
+  if (!ap) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   dim3 grid((unsigned)(ap->m_tiles * ap->n_tiles * ap->ksplit));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, *ap);
   return hipGetLastError();
 }
+template <typename DT> static hipError_t launch_g2(int tile, const ConvArgs* ap, size_t lds, hipStream_t st) {
+  if (!ap) {   // one-time attributes of every instantiation
+    hipError_t e = launch_g2_tile<DT, TILE_128x64>(ap, lds, st);
+    if (e == hipSuccess) e = launch_g2_tile<DT, TILE_256x32>(ap, lds, st);
+    if (e == hipSuccess) e = launch_g2_tile<DT, TILE_128x32>(ap, lds, st);
+    return e;
+  }
+  return tile == TILE_256x32 ? launch_g2_tile<DT, TILE_256x32>(ap, lds, st)
+       : tile == TILE_128x32 ? launch_g2_tile<DT, TILE_128x32>(ap, lds, st) : launch_g2_tile<DT, TILE_128x64>(ap, lds, st);
+}
 
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a) {
   if (a.cpg == 2 && ks == 3 && stride == 1) return conv_g2_lds_bytes(tile, a);
-  if (tile < 0 || tile >= TILE_COUNT) return 0;
+  if (tile < 0 || tile >= TILE_COUNT || tile == TILE_256x32) return 0;   // (256 x 32 exists as the two-chunk variant only)
   if (!(ks == 1 || ks == 3) || !(stride == 1 || (stride == 2 && ks == 3 && tile == TILE_64x64))) return 0;
   const ConvTileInfo ti = conv_tile_info(tile);
   if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != ti.BM) return 0;
@@ -1910,7 +1982,7 @@ hipError_t launch_conv(int dtype, int tile, int ks, int stride, const ConvArgs& 
   const size_t lds = conv_lds_bytes(dtype, tile, ks, stride, a);
   if (lds == 0 || a.ksplit < 1 || a.n_tiles < 1) return hipErrorInvalidValue;
   if (a.cpg == 2)
-    return dtype == 1 ? launch_g2<__bf16>(&a, lds, st) : dtype == 2 ? launch_g2<_Float16>(&a, lds, st) : launch_g2<float>(&a, lds, st);
+    return dtype == 1 ? launch_g2<__bf16>(tile, &a, lds, st) : dtype == 2 ? launch_g2<_Float16>(tile, &a, lds, st) : launch_g2<float>(tile, &a, lds, st);
   return dtype == 1 ? launch_dt<__bf16>(tile, ks, stride, &a, lds, st)
        : dtype == 2 ? launch_dt<_Float16>(tile, ks, stride, &a, lds, st)
                     : launch_dt<float>(tile, ks, stride, &a, lds, st);
@@ -1957,7 +2029,9 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   const size_t bufb = (size_t)(ph << a.tb_log2) * a.lds_row;
   const size_t rawb = (size_t)ws_nit(dtype, tile, ks) * (kWsLoaderWaves * 64 * 16);
   const size_t affb = a.has_gn ? (((size_t)2 * (a.C0 + a.C1) * 4 + 15) & ~(size_t)15) : 0;  // never keyed on a pointer
-  const size_t total = 2 * bufb + 3 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb;
+  const WsTileCfg wt = ws_tile(tile);
+  const size_t nbuf = (size_t)ws_nbuf(32 * wt.MB * wt.WM, ks, wt.NB);
+  const size_t total = nbuf * bufb + 3 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb + (nbuf >= 3 ? 32 : 0);
   if (a.tb_log2 != 0 || a.kchunks / conv_cpg(ks) < 2) return 0;   // one image per tile, >= 2 channel groups
   // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
   if ((long long)a.B * a.Ho * a.Wo * std::max(a.out_ld, a.resid_ld) >= (1LL << 31)) return 0;   // 32-bit element offsets
@@ -2032,9 +2106,9 @@ hipError_t conv_init() {
           }
         }
   {
-    hipError_t e = launch_g2<float>(nullptr, 0, nullptr);
-    if (e == hipSuccess) e = launch_g2<__bf16>(nullptr, 0, nullptr);
-    if (e == hipSuccess) e = launch_g2<_Float16>(nullptr, 0, nullptr);
+    hipError_t e = launch_g2<float>(0, nullptr, 0, nullptr);
+    if (e == hipSuccess) e = launch_g2<__bf16>(0, nullptr, 0, nullptr);
+    if (e == hipSuccess) e = launch_g2<_Float16>(0, nullptr, 0, nullptr);
     if (e != hipSuccess) return e;
   }
   for (int ks = 1; ks <= 3; ks += 2) {

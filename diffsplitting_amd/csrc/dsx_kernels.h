@@ -203,7 +203,7 @@ struct ConvArgs {
 };
 
 // tile configurations compiled for the MFMA conv kernel
-enum ConvTile { TILE_256x128 = 0, TILE_128x128, TILE_64x128, TILE_256x64, TILE_128x64, TILE_64x64, TILE_128x32, TILE_COUNT };
+enum ConvTile { TILE_256x128 = 0, TILE_128x128, TILE_64x128, TILE_256x64, TILE_128x64, TILE_64x64, TILE_128x32, TILE_256x32, TILE_COUNT };
 struct ConvTileInfo { int BM, BN; };
 ConvTileInfo conv_tile_info(int tile);
 int conv_tile_wm(int tile);   // waves along M (one statistics row per (tile, wm))
@@ -213,7 +213,8 @@ int conv_ws_tile_wm(int tile);          // k_conv_ws lays its waves out differen
 // input-channel chunks are staged in groups of this many (weights are packed/padded to it)
 int conv_chunk_multiple(int ks);
 int conv_lds_row(int ks, int stride, int tw_log2);
-// two-chunk-per-group 3x3 variant of k_conv_mfma (ConvArgs::cpg == 2), TILE_128x64 only
+// two-chunk-per-group 3x3 variant of k_conv_mfma (ConvArgs::cpg == 2): TILE_128x64 (experiment) and the narrow-output
+// tiles TILE_256x32 / TILE_128x32 (convs with <= 32 output channels, e.g. the UNet's final conv)
 int conv_lds_row_g2(int tw_log2);
 size_t conv_g2_lds_bytes(int tile, const ConvArgs& a);
 // LDS bytes needed by a launch; 0 if the geometry is not supported by `tile`

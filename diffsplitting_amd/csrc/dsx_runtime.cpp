@@ -792,6 +792,33 @@ static bool pick_conv(int dtype, int ks, int stride, ConvArgs& a, int& tile_out)
       if (conv_g2_lds_bytes(tile, g) != 0 && g.m_tiles >= 512) { a = g; tile_out = tile; return true; }
     }
   }
+  // Narrow outputs (<= 32 channels: the UNet's final conv, 64 -> 3 at full resolution): HBM-bound layers that the
+  // generic 128 x 32 tile walked as two 32-channel groups with a barrier pair each and a 16 x 8 pixel halo.  The
+  // two-chunk variant stages ALL input channels of a 16 x 16 (or 16 x 8) pixel patch once -- one load phase, one
+  // conversion, one barrier, 36 MFMA steps per row block -- with three workgroups per CU overlapping their phases.
+  static const int narrow_on = getenv("DSX_NARROW_G2") ? atoi(getenv("DSX_NARROW_G2")) : 1;
+  {
+    const int gw2 = 2 * (dtype != DSX_DTYPE_F32 ? 32 : 16);          // channels per two-chunk group
+    if (narrow_on && ks == 3 && stride == 1 && a.Cout <= 32 && a.stage_mode == 0 && a.kchunks % 2 == 0 &&
+        a.C0 % gw2 == 0 && a.C1 % gw2 == 0 && !a.up) {
+      static const std::vector<int> narrow_tiles = tile_order("DSX_TILES_NARROW_G2", {TILE_256x32, TILE_128x32});
+      for (int tile : narrow_tiles) {
+        ConvArgs g = a;
+        const ConvTileInfo ti = conv_tile_info(tile);
+        const int TW = pow2_divisor(a.Wo, 16), TH = pow2_divisor(a.Ho, std::max(1, ti.BM / TW));
+        if (TW * TH != ti.BM) continue;
+        g.cpg = 2;
+        g.tw_log2 = ilog2(TW); g.th_log2 = ilog2(TH); g.tb_log2 = 0;
+        g.tiles_x = a.Wo / TW; g.tiles_y = a.Ho / TH;
+        g.m_tiles = g.tiles_x * g.tiles_y * a.B;
+        g.n_tiles = 1;
+        g.ksplit = 1; g.groups_per_split = a.kchunks / 2; g.slab_stride = 0;
+        g.lds_row = conv_lds_row_g2(g.tw_log2);
+        g.ablate = 0;
+        if (conv_g2_lds_bytes(tile, g) != 0) { a = g; tile_out = tile; return true; }
+      }
+    }
+  }
   static const int ws_1x1 = getenv("DSX_WS_1X1") ? atoi(getenv("DSX_WS_1X1")) : 1;
   if (ws_on && (ks != 1 || ws_1x1) && stride == 1 && a.stage_mode == 0) {
     for (int tile : (is_wide ? ws_wide : ws_narrow)) {
