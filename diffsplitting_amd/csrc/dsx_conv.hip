@@ -42,6 +42,9 @@
 #ifndef DSX_PF
 #define DSX_PF 2
 #endif
+#ifndef DSX_WS_K0_EXPR
+#define DSX_WS_K0_EXPR 64   // raw groups requested before the first wait (>= P + 1: the whole ring, the round-2 behaviour)
+#endif
 #ifndef DSX_EPI_PRIO_COND
 #define DSX_EPI_PRIO_COND false
 #endif
@@ -1063,25 +1066,31 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       if (++slotF == NSLOT) slotF = 0;
     };
     DSX_STAMP_T(110, tid == 256);       // tables built
-    while (issued < NSLOT && issued < total) issue_next();
+    // Start-up ramp: with every CU issuing at once an LDS-DMA instruction takes ~200 cycles to issue, and the first
+    // item's data has landed long before all P + 1 ring slots are requested.  Only the first K0 items are requested
+    // up front; the ring fills up (at most two requests per iteration) while the first images are converted.
+    // `young` of a wait is counted from `issued`: requests issued after the item waited for.
+    constexpr int K0 = DSX_WS_K0_EXPR < NSLOT ? DSX_WS_K0_EXPR : NSLOT;
+    while (issued < K0 && issued < total) issue_next();
     DSX_STAMP_T(111, tid == 256);       // first DMAs issued
     ws_barrier();                       // scale/shift of tiles 0 and 1 are in LDS
-    wait_young(min(P, total - 1));
+    wait_young(issued - 1);
     DSX_STAMP_T(112, tid == 256);       // item 0 has landed
     fetch_next();                       // item 0
+    for (int k = 0; k < 2 && issued < total && issued < NSLOT; ++k) issue_next();   // (in flight during the conversion)
     convert(0);
     if constexpr (NBUF >= 3) { if (total > 0) lds_signal(full_addr, wave, 1); }   // item 0 is ready
     DSX_STAMP_T(113, tid == 256);       // item 0 converted
     if (total > 1) {
-      wait_young(min(P - 1, total - 2));
+      wait_young(issued - 2);
       fetch_next();                     // item 1
     }
     if constexpr (NBUF == 2) ws_barrier();   // image of item 0 is ready
     DSX_STAMP_T(64, tid == 256);
     int bufL = 1;                       // image buffer of item v + 1
     for (int v = 0; v < total; ++v) {
-      // the slot of item v was copied to registers two iterations ago: reuse it for item v+NSLOT
-      if (issued < total) issue_next();
+      // the slots of items <= v were copied to registers an iteration or more ago: items up to v + NSLOT may be requested
+      for (int k = 0; k < 2 && issued < total && issued < v + 1 + NSLOT; ++k) issue_next();
       DSX_STAMP_T(65 + 4 * v, tid == 256 && v < 9);
       if (v + 1 < total) {
         if constexpr (NBUF >= 3) {
@@ -1096,7 +1105,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       if (++bufL == NBUF) bufL = 0;
       DSX_STAMP_T(66 + 4 * v, tid == 256 && v < 9);
       if (v + 2 < total) {
-        wait_young(min(P - 1, total - 3 - v));
+        wait_young(issued - (v + 3));
         fetch_next();                   // item v+2
       }
       DSX_STAMP_T(67 + 4 * v, tid == 256 && v < 9);
