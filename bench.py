@@ -281,13 +281,23 @@ def main():
     if args.dry:
         return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one GPU per rank; DSX_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (the ranks
+    # share them, collectives staged through the host; the JSON line then says so and is not a scaling measurement)
+    backend = os.environ.get("DSX_DIST_BACKEND") or "nccl"
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"--gpus {world} but {ndev} GPU(s) visible: RCCL needs one device per rank")
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    on_host = dist is not None and backend != "nccl"     # gloo: reductions / gathers of device tensors go through the host
     torch.set_grad_enabled(False)
 
     from diffsplitting_amd import engine
@@ -346,13 +356,14 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the sampler's only exchange: one all-gather of the finished images (outside the loop)
-        out = torch.empty((world * B, 3, 128, 128), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(out, x.contiguous())
-        x = out
+        src = x.contiguous().cpu() if on_host else x.contiguous()
+        out = torch.empty((world * B, 3, 128, 128), dtype=torch.float32, device=src.device)
+        dist.all_gather_into_tensor(out.view(-1), src.view(-1))
+        x = out.to(dev)
     assert torch.isfinite(x).all(), "sampler produced non-finite pixels"
 
     ms_per_step = elapsed * 1e3 / K
@@ -365,7 +376,9 @@ def main():
         "config": {"workload": "sr_sr3_16_128: GaussianDiffusion.p_sample_loop, 16->128 SR3 UNet (97.8M params), "
                                "T=2000 linear schedule; one step = UNet forward + posterior update of the batch",
                    "batch_per_gpu": B, "global_batch": world * B, "image": "128x128x3", "sample_steps": SAMPLE_STEPS,
-                   "parallelism": f"{world} independent replicas, final RCCL all-gather", "hipgraph": use_graph, "streams": nsplit,
+                   "parallelism": f"{world} independent replicas, final RCCL all-gather" if backend == "nccl" else
+                                  f"{world} ranks sharing {ndev} GPU(s), {backend} transport through the host: a REHEARSAL of the N > 1 path, not a scaling measurement",
+                   "hipgraph": use_graph, "streams": nsplit,
                    "noise": "device Philox4x32-10", "weights": "random-init, seed 0"},
     }
     if rank == 0:

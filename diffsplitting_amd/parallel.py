@@ -23,11 +23,22 @@ def init(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        backend = os.environ.get("DSX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        # one GPU per rank; with fewer GPUs than ranks (rehearsals of the N > 1 path on a one-GPU box, gloo transport)
+        # the ranks share them -- RCCL itself refuses two ranks on one device
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(backend=backend)
     return rank(), world_size()
+
+
+def _gather_through_host(flat, group):
+    """gloo has no all_gather_into_tensor for device tensors: stage through the host (rehearsal transport only)."""
+    world = dist.get_world_size(group)
+    src = flat.detach().to("cpu").contiguous().view(-1)
+    out = torch.empty(world * src.numel(), dtype=src.dtype)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out.to(flat.device)
 
 
 def free_port():
@@ -146,6 +157,8 @@ def all_gather_flat(flat, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return flat.view(1, -1)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        return _gather_through_host(flat, group).view(world, -1)
     out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat.contiguous().view(-1), group=group)
     return out.view(world, -1)

@@ -17,8 +17,7 @@ def main():
     from tests.test_gpu_boundary import _opt, _tiny_indi_section
     from tests.util import golden_state_dict
     torch.set_grad_enabled(False)
-    rank, world = parallel.init("nccl")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world = parallel.init(os.environ.get("DSX_DIST_BACKEND") or "nccl")   # (sets the rank's device)
     sd, _ = golden_state_dict("unet_hagen_64")
     sec = _tiny_indi_section()
     sec["unet"]["channel_multiplier"] = [1, 2, 4, 8]
@@ -36,7 +35,7 @@ def main():
         outs.append(netG.last_full_batch.clone())
     ref = plan.stitch(torch.cat(outs))
     ok = torch.equal(pred, ref)
-    flag = torch.tensor([1 if ok else 0], device="cuda")
+    flag = torch.tensor([1 if ok else 0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
         print("PREDICT_TILED_OK" if int(flag.item()) == 1 else "PREDICT_TILED_MISMATCH", plan.total, world)

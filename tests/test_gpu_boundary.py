@@ -218,6 +218,42 @@ def test_two_rank_predict_tiled():
     assert r.returncode == 0 and "PREDICT_TILED_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_share_the_one_gpu_gloo_transport(world):
+    """The N > 1 tiled path on the hardware that is there: `world` fresh ranks (parallel.self_launch), every rank its own
+    libdsx / executors / tile shard on the ONE GPU, valid regions packed on the device, the exchange over gloo (staged
+    through the host: RCCL refuses two ranks on one device), paste from the packed layout -- stitched result bitwise
+    equal to the one-rank prediction on every rank.  What stays unexecuted on hardware is the RCCL transport itself."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom diffsplitting_amd import parallel\n"
+            "sys.exit(parallel.self_launch(%d, [%r], timeout=500))\n" % (root, world, os.path.join(root, "tests", "multi_gpu_predict_tiled.py")))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DSX_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PREDICT_TILED_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_bench_two_ranks_share_the_one_gpu_gloo_transport():
+    """`python bench.py --gpus 2` on the hardware that is there: self-launch, per-rank device / library state, barriers,
+    MAX over ranks and the final gather of the images all run (gloo through the host instead of RCCL); the line says it
+    is a rehearsal.  Both ranks run the B = 16 loop on the one GPU at once."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DSX_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+                        "--no-roofline", "--no-cpu-baseline", "--no-fp32-parity"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and "REHEARSAL" in line["config"]["parallelism"]
+    assert line["config"]["global_batch"] == 32 and line["value"] > 0
+
+
 def test_stitch_with_fused_range_invariant_psnr():
     """N1: the quality metric accumulated while stitching (no second pass over the canvas).  Fixture: psnr.npz holds
     gt / pred and RangeInvariantPsnr as the reference's core/psnr.py computed them; the prediction is cut into tiles,
