@@ -365,6 +365,7 @@ def main():
         dist.all_gather_into_tensor(out.view(-1), src.view(-1))
         x = out.to(dev)
     assert torch.isfinite(x).all(), "sampler produced non-finite pixels"
+    assert eng.handoff_timeouts() == 0, "a bounded hand-off spin of k_conv_ws gave up: the timed pixels are wrong"
 
     ms_per_step = elapsed * 1e3 / K
     images_per_s = world * B / (ms_per_step * 1e-3 * SAMPLE_STEPS)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "dsx_exec_create": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
     "dsx_exec_destroy": (None, [_vp]),
     "dsx_exec_workspace_bytes": (C.c_size_t, [_vp]),
+    "dsx_exec_handoff_timeouts": (_i, [_vp, C.POINTER(C.c_uint)]),
     "dsx_plan_dry_run": (_i, [C.POINTER(UnetCfg), _i, _i, _i, _i, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                               C.POINTER(_i)]),
     "dsx_exec_num_launches": (_i, [_vp]),

@@ -39,8 +39,8 @@
 #ifndef DSX_PRE_RESID_EXPR
 #define DSX_PRE_RESID_EXPR (NB == 1 && MB <= 2)   // (MB 4 with 16-bit storage fits the registers but measured 3 % slower)
 #endif
-#ifndef DSX_PF
-#define DSX_PF 2
+#ifndef DSX_PFF_EXPR
+#define DSX_PFF_EXPR (NB == 2 ? 3 : 6)   // k_conv_ws: pixel fragments in flight ahead of the MFMAs (~190 cycles of MFMA work)
 #endif
 #ifndef DSX_WS_K0_EXPR
 #define DSX_WS_K0_EXPR 64   // raw groups requested before the first wait (>= P + 1: the whole ring, the round-2 behaviour)
@@ -313,6 +313,80 @@ __device__ __forceinline__ f32x16 mfma_step(const uint4 w, const f32x4_t px, f32
   }
 }
 
+// k_conv_ws multiplies with the 16 x 16 MFMA shapes (v_mfma_f32_16x16x32_bf16 / _f16, 16x16x4 f32): the same FLOP per
+// cycle, operand bytes and accumulator registers as 32x32x16, but the chip holds a higher clock under them
+// (MI355X_MICROARCH.md, DVFS give-back 7; measured here with a probe build before the re-layout: every 3 x 3 launch
+// -3.6 .. -4.2 %, the 2000-step loop -4.1 %, profiles/r03_ab_experiments.md).
+//   A (weights): lane (i = lane & 15, kq = lane >> 4) = output channel row i, K slice kq (16 bytes);
+//   B (pixels):  lane (c, kq) = pixel column c, K slice kq;   D: lane (c, kq), register j = row 4 kq + j of column c.
+// The 16-byte K slice of a 64-byte chunk that lane group kq multiplies is slice ws16_slice(kq) = {0, 2, 1, 3}[kq] and
+// column c is pixel ws16_pixel(c) of a 16-pixel block -- the b128 read groups of the LDS ({0-3,12-15,20-27}, ...) then
+// pair 8 even pixels at one slice with the 8 odd pixels two slices on: 16 distinct 16-byte bank groups for the pixel
+// pitches used here (80 / 144 bytes; the row pitches of conv_lds_row keep the parity).
+// One fragment per lane pair (ch = 0, 1) covers a 32-channel N block: row i of fragment ch is channel
+// 8 (i / 4) + 4 ch + i % 4, so a lane ends up with 8 consecutive channels 8 kq .. 8 kq + 7 of ONE pixel per 16-pixel
+// block (registers 8 ph + 4 ch + j of the f32x16: ph = which half of the 32-pixel row block).
+__host__ __device__ constexpr int ws16_slice(int kq) { return ((kq & 1) << 1) | (kq >> 1); }
+__device__ __forceinline__ int ws16_pixel(int c) { return c < 4 ? 2 * c : (c < 12 ? 2 * (c - 4) + 1 : 2 * (c - 8)); }
+// byte offset of lane (i, kq)'s 16 bytes of fragment ch inside the 2 KiB (tap, chunk) pair of pack_conv's stream
+// ([half fs][lane (i_old, h)][16 B]: K slice s is half s / 2, lane half s % 2; channel 16 hh + 4 jj + q is row q + 8 jj + 4 hh)
+__device__ __forceinline__ int ws16_woff(int lane, int ch) {
+  const int i = lane & 15, sl = ws16_slice(lane >> 4);
+  const int i_old = (i & 3) + 16 * ((i >> 2) & 1) + 8 * ch + 4 * (i >> 3);
+  return (sl >> 1) * 1024 + ((sl & 1) * 32 + i_old) * 16;
+}
+template <typename DT>
+__device__ __forceinline__ f32x4_t mfma16_step(const uint4 w, const f32x4_t px, f32x4_t acc) {
+  if constexpr (Kind<DT>::value == 1) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, px), acc, 0, 0, 0);
+  } else if constexpr (Kind<DT>::value == 2) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, px), acc, 0, 0, 0);
+  } else {
+    const float4 af = __builtin_bit_cast(float4, px);
+    const float4 bf = __builtin_bit_cast(float4, w);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.x, af.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.y, af.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.z, af.z, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(bf.w, af.w, acc, 0, 0, 0);
+  }
+}
+// 8 per-lane registers -> the 16-lane DPP row's total of ONE register per lane: lane i ends up with register
+// row8_fold_reg(i) summed over the row (three halving butterfly stages, then lane ^ 8): 7 + 1 adds
+__device__ __forceinline__ float row8_fold(const float (&s)[8], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  float a4[4], a2[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float keep = b0 ? s[k + 4] : s[k], send = b0 ? s[k] : s[k + 4];
+    a4[k] = keep + dpp_take<0xB1, 0xF>(0.f, send);                       // lane ^ 1
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float keep = b1 ? a4[k + 2] : a4[k], send = b1 ? a4[k] : a4[k + 2];
+    a2[k] = keep + dpp_take<0x4E, 0xF>(0.f, send);                       // lane ^ 2
+  }
+  const float keep = b2 ? a2[1] : a2[0], send = b2 ? a2[0] : a2[1];
+  float t = dpp_take<0x104, 0x5>(0.f, send);                             // banks 0,2 <- lane + 4
+  t = dpp_take<0x114, 0xA>(t, send);                                     // banks 1,3 <- lane - 4
+  const float a1 = keep + t;
+  return a1 + dpp_take<0x128, 0xF>(0.f, a1);                             // lane ^ 8 (row_ror:8)
+}
+__device__ __forceinline__ int row8_fold_reg(int lane) { return 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1); }
+// x[8] = 8 consecutive channels of one pixel -> out in the storage type (16-byte vector stores)
+__device__ __forceinline__ void store8(void* out, size_t elem, const float (&x)[8], int kind) {
+  if (kind == 1) {
+    *(uint4*)((unsigned short*)out + elem) =
+        make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+  } else if (kind == 2) {
+    *(uint4*)((unsigned short*)out + elem) =
+        make_uint4(pack_f16x2(x[0], x[1]), pack_f16x2(x[2], x[3]), pack_f16x2(x[4], x[5]), pack_f16x2(x[6], x[7]));
+  } else {
+    float4* q = (float4*)((float*)out + elem);
+    q[0] = make_float4(x[0], x[1], x[2], x[3]);
+    q[1] = make_float4(x[4], x[5], x[6], x[7]);
+  }
+}
+
 // Loader -> compute hand-off of k_conv_ws.  NBUF == 2: two MFMA images, one workgroup barrier per (tile, group) item
 // (strict alternation).  NBUF == 3 / 4: three / four images and LDS counters instead of the barrier -- FULL (one per
 // loader wave: items converted) and FREE (one per compute wave: items consumed): the loaders may run two items
@@ -328,7 +402,7 @@ __device__ __forceinline__ f32x16 mfma_step(const uint4 w, const f32x4_t px, f32
 static constexpr int ws_nbuf(int bm, int ks, int nb) { return DSX_WS_NBUF_EXPR(bm, ks, nb); }
 // a counter PER WAVE (four words, read with one ds_read_b128): a single shared counter would let three fast waves
 // stand in for a slow one, and the image of the item that one is still reading would be overwritten
-static __device__ __forceinline__ void lds_wait_all_ge(unsigned addr, int target) {
+static __device__ __forceinline__ void lds_wait_all_ge(unsigned addr, int target, unsigned* timeouts) {
   for (int spin = 0; spin < (1 << 18); ++spin) {   // ~30 ms: a hand-off normally takes microseconds
     f32x4_t v;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
@@ -337,6 +411,8 @@ static __device__ __forceinline__ void lds_wait_all_ge(unsigned addr, int target
     if (__builtin_amdgcn_readfirstlane(m) >= target) return;
     __builtin_amdgcn_s_sleep(1);
   }
+  // gave up: the pixels of this launch are wrong -- say so (the host reads the counter: dsx_exec_handoff_timeouts)
+  if (timeouts != nullptr && (threadIdx.x & 63) == 0) atomicAdd(timeouts, 1u);
 }
 static __device__ __forceinline__ void lds_signal(unsigned addr, int wave, int count) {   // this wave's word := count, behind its own LDS traffic
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -801,7 +877,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   const bool loader = wave8 >= 4;
   const int wave = loader ? wave8 - 4 : wave8;  // index inside the role
   const int ltid = loader ? tid - 256 : tid;
-  const int li = lane & 31, lh = lane >> 5;
+  const int c16 = lane & 15, kq = lane >> 4;     // compute waves: MFMA column (pixel) / K slice and output row group (see mfma16_step)
 
   const int TW = 1 << a.tw_log2, TH = 1 << a.th_log2;
   const int PW = (TW - 1) * S + KS;
@@ -964,7 +1040,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
         // the scale/shift slot of tile t (t >= 3) is written by the compute waves' epilogue of tile t - 3, which is
         // over once they have consumed the first item of tile t - 2 (with the per-item barrier of NBUF == 2 the
         // three-tile lead alone guarantees this; running ahead, the loaders ask)
-        if (gnF && gC == 0 && tiC >= 3) lds_wait_all_ge(full_addr + 16, (tiC - 2) * G + 1);
+        if (gnF && gC == 0 && tiC >= 3) lds_wait_all_ge(full_addr + 16, (tiC - 2) * G + 1, a.handoff_timeouts);
       }
       const unsigned src = lds0 + NBUF * BUFB + 3 * AFFB + slot * RAWB + ltid * 16;
       if (gnF) {
@@ -1095,7 +1171,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       if (v + 1 < total) {
         if constexpr (NBUF >= 3) {
           // buffer (v + 1) % NBUF held item v + 1 - NBUF: every compute wave must have released it (v + 2 - NBUF items consumed)
-          if (v + 1 >= NBUF) lds_wait_all_ge(full_addr + 16, v + 2 - NBUF);
+          if (v + 1 >= NBUF) lds_wait_all_ge(full_addr + 16, v + 2 - NBUF, a.handoff_timeouts);
           convert(bufL);
           lds_signal(full_addr, wave, v + 2);     // items 0 .. v + 1 are ready
         } else {
@@ -1116,40 +1192,47 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   }
 
   // ========================================================================= COMPUTE WAVES
-  // Each wave owns MB row blocks x NB 32-channel N blocks.  With NB = 2 a pixel fragment read from LDS
-  // feeds two MFMAs (LDS operand traffic per MFMA halves) and one converted group of the loaders feeds twice
-  // the MFMA work.
+  // Each wave owns MB row blocks of 32 pixels (two 16-pixel MFMA column blocks, ph = 0 / 1) x NB 32-channel N blocks.
+  // A pixel fragment read from LDS feeds 2 NB MFMAs (both 16-channel halves of every N block).
   const int wm = wave / WN, wn = wave % WN;
-  int abase[MB][KS];
+  const int pq = ws16_pixel(c16);               // this lane's pixel inside a 16-pixel block
+  int abase[MB][KS];                            // ph = 0; the ph = 1 block is `a16` bytes further (uniform)
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int m = (wm * MB + mb) * 32 + li;
+    const int m = (wm * MB + mb) * 32 + pq;
     const int tx = m & (TW - 1);
     const int ty = (m >> a.tw_log2) & (TH - 1);
     const int tb = m >> (a.tw_log2 + a.th_log2);
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy)
-      abase[mb][dy] = (tb * PH + ty * S + dy) * RB + tx * S * PIXB + lh * 16;
+      abase[mb][dy] = (tb * PH + ty * S + dy) * RB + tx * S * PIXB + ws16_slice(kq) * 16;
   }
+  // pixel m + 16 of a row block: 16 pixels to the right (tiles >= 32 wide), else 16 / TW rows down (host: TW >= 8, TB == 1)
+  const int a16 = TW >= 32 ? 16 * S * PIXB : (16 >> a.tw_log2) * S * RB;
   const int blk0 = (nt * WN + wn) * NB;         // host: Cout % (32 * WN * NB) == 0, so every block exists
   const int wblock = G * (NSTEP * 1024);        // bytes of one N block's fragment stream
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const unsigned char*)a.wpack + (size_t)blk0 * wblock), 0, NB * wblock, 0x00020000);
-  const int wlane = lane * 16;
+  // pack_conv's stream holds, per (chunk, tap), two 1 KiB fragments of the 32x32x16 shape; the 16 x 16 fragments ch = 0 / 1
+  // of the same 32 channels x 32 K are a per-lane gather from that 2 KiB pair (every byte of it is read exactly once)
+  const int wlane[2] = {ws16_woff(lane, 0), ws16_woff(lane, 1)};
+  static_assert(D % 2 == 0 && NSTEP % 2 == 0, "ring slots alternate between the two fragments of a pair");
   const int qtot = G * NSTEP;                   // the stream restarts at every tile (same N blocks)
-  int qn = 0;                                   // next step to prefetch (wraps)
+  int qn = 0;                                   // next step (fragment) to prefetch (wraps); its parity is the static `ch`
   struct WFrag { uint4 v[NB]; };                // one step's weight fragments (by value: stays in registers)
-  auto load_b = [&]() __attribute__((always_inline)) -> WFrag {
+  auto load_b = [&](auto chc) __attribute__((always_inline)) -> WFrag {
+    constexpr int ch = decltype(chc)::value;
     WFrag f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-      f.v[nb] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, nb * wblock + qn * 1024, 0));
+      f.v[nb] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane[ch], nb * wblock + (qn >> 1) * 2048, 0));
     if (++qn == qtot) qn = 0;
     return f;
   };
   WFrag bq[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) bq[j] = load_b();
+  static_for<D>([&](auto jc) __attribute__((always_inline)) {
+    bq[decltype(jc)::value] = load_b(std::integral_constant<int, (decltype(jc)::value & 1)>{});
+  });
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -1160,7 +1243,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
   const bool do_stats = a.stat_part != nullptr;
-  const int nbase = blk0 * 32 + 16 * lh;        // this lane's 16 consecutive channels of N block 0 (+32 per block)
+  const int nbase = blk0 * 32 + 8 * kq;         // this lane's 8 consecutive channels of N block 0 (+32 per block)
 
   // Tile walk without divisions: (tx, ty, image) of tile p0 + k*wpn, advanced by the decomposed stride.
   struct TilePos { int tx, ty, b; };
@@ -1175,14 +1258,16 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   };
   // element offsets (32-bit; host: tensors < 2^31 elements) of this lane's output rows: a tile-invariant
   // per-row part, precomputed, plus a wave-uniform per-tile part -> no per-tile vector multiplies
-  int orow[MB], rrow[MB];
+  int orow[MB], rrow[MB];                       // ph = 0; the pixel of ph = 1 is `p16` output pixels further (uniform)
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int m = (wm * MB + mb) * 32 + li;
+    const int m = (wm * MB + mb) * 32 + pq;
     const int pix = (m >> a.tw_log2) * a.Wo + (m & (TW - 1));
     orow[mb] = pix * a.out_ld + nbase;
     rrow[mb] = pix * a.resid_ld + nbase;
   }
+  const int p16 = TW >= 32 ? 16 : (16 >> a.tw_log2) * a.Wo;
+  const int o16 = p16 * a.out_ld, r16 = p16 * a.resid_ld;
   auto tile_pixel0 = [&](const TilePos& t) __attribute__((always_inline)) -> int {   // first output pixel of tile t (uniform)
     return (t.b * a.Ho + (t.ty << a.th_log2)) * a.Wo + (t.tx << a.tw_log2);
   };
@@ -1221,30 +1306,32 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   // One per-channel addend: the FiLM vector of the tile's image (the host folds the conv bias into the FiLM
   // bias, see dsx_model_finalize) or, without FiLM, the conv bias, fetched once (the workgroup never changes
   // its N tile).  Missing operands stay 0.0f: adding them is exact.
-  constexpr int NR = 16 / CPU;   // 16-byte pieces of a lane's 16 residual values
+  constexpr int NR = 8 / CPU;    // 16-byte pieces of a lane's 8 residual values of one pixel
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 addv[NB][4], affv[2];
+  float4 addv[NB][2], affv[2];
   constexpr bool PRE_RESID = DSX_PRE_RESID_EXPR;   // else the residual is read in the epilogue
-  uint4 residv[PRE_RESID ? MB : 1][NB][NR];      // storage type; all-zero bits are 0.0 in both
+  uint4 residv[PRE_RESID ? MB : 1][NB][2][NR];   // [row block][N block][ph][piece]; storage type; all-zero bits are 0.0 in both
   // (a uniform branch, not `cond ? *ptr : zero4`: hipcc turns that select into a flat load through a pointer select
   // between the global vector and a private copy of zero4 -- scratch, flat loads, and the addrspacecast that its spill
   // path later fails on with "Operand has incorrect register class ... $src_private_base")
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) addv[nb][j] = zero4;
+    for (int j = 0; j < 2; ++j) addv[nb][j] = zero4;
   if (a.bias && !a.film) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) addv[nb][j] = *(const float4*)(a.bias + nbase + 32 * nb + 4 * j);
+      for (int j = 0; j < 2; ++j) addv[nb][j] = *(const float4*)(a.bias + nbase + 32 * nb + 4 * j);
   }
 #pragma unroll
   for (int mb = 0; mb < (PRE_RESID ? MB : 1); ++mb)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int q = 0; q < NR; ++q) residv[mb][nb][q] = make_uint4(0u, 0u, 0u, 0u);
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int q = 0; q < NR; ++q) residv[mb][nb][ph][q] = make_uint4(0u, 0u, 0u, 0u);
   affv[0] = affv[1] = zero4;
   // t: the tile whose epilogue will use the operands; b_aff: image of the tile three after it
   auto prefetch_epilogue = [&](const TilePos& t, bool want_aff, int b_aff) __attribute__((always_inline)) {
@@ -1252,19 +1339,21 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
           addv[nb][j] = *(const float4*)(a.film + (size_t)t.b * a.film_bs + nbase + 32 * nb + 4 * j);
     }
     if (PRE_RESID && a.resid) {
       const int r0 = tile_pixel0(t) * a.resid_ld;
 #pragma unroll
-      for (int mb = 0; mb < (PRE_RESID ? MB : 1); ++mb) {
-        const DT* rp = (const DT*)a.resid + (r0 + rrow[mb]);
+      for (int mb = 0; mb < (PRE_RESID ? MB : 1); ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int ph = 0; ph < 2; ++ph) {
+          const DT* rp = (const DT*)a.resid + (r0 + rrow[mb] + ph * r16);
 #pragma unroll
-          for (int q = 0; q < NR; ++q) residv[mb][nb][q] = *(const uint4*)(rp + 32 * nb + CPU * q);
-      }
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) residv[mb][nb][ph][q] = *(const uint4*)(rp + 32 * nb + CPU * q);
+        }
     }
     if (want_aff && a.gn_scale != nullptr && tid * 4 < C) {
       affv[0] = *(const float4*)(a.gn_scale + (size_t)b_aff * C + tid * 4);
@@ -1300,8 +1389,13 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   DSX_STAMP_T(0, tid == 0);
   int g = 0, ti = 0, aslot = 0;   // aslot == ti % 3
   int ibuf = 0;                   // image buffer of the current item (v % NBUF)
-  constexpr int PF = NB == 2 ? 1 : DSX_PF;         // operand fragments are read PF steps ahead of their MFMAs (a step is NB x longer)
-  static_assert(PF < NSTEP && PF * MB <= 15, "lgkmcnt is 4 bits");
+  // operand fragments (one 16-pixel column block x one 64-byte chunk each, feeding 2 NB MFMAs = 32 NB cycles) are read
+  // PFF fragments ahead of their MFMAs into a ring of PFF + 1
+  constexpr int NPAIR = NSTEP / 2;                 // (chunk, tap) pairs of an item: two weight fragments (ch = 0, 1) each
+  constexpr int NF = 2 * MB;                       // pixel fragments per pair: (mb, ph)
+  constexpr int FT = NPAIR * NF;                   // pixel fragments per item
+  constexpr int PFF = (DSX_PFF_EXPR) < FT ? (DSX_PFF_EXPR) : FT - 1;
+  static_assert(PFF >= 1 && PFF < FT && PFF <= 15, "lgkmcnt is 4 bits");
   // The ring slot of step s of item v is (v * NSTEP + s) % D: static for D <= NSTEP; for a ring of RP groups the item
   // loop is unrolled RP times (ring phase R = v % RP static in each copy).
   constexpr int RP = D > NSTEP ? D / NSTEP : 1;

@@ -185,6 +185,8 @@ struct ConvArgs {
   unsigned mg_tiles_x, mg_per_img, mg_pw, mg_wpn, mg_per;   // fastdiv magics (dividends < 65536, see fastdiv)
   int ws_bigdiv;          // m_tiles + wpn >= 65536: the tiles-per-workgroup quotient needs a real division
   float* stat_part;       // fused GroupNorm partials [B][tiles_x*tiles_y*WM][Cout][2] (fp32) or nullptr
+  unsigned* handoff_timeouts;  // k_conv_ws with image counters: incremented when a bounded FULL / FREE spin gives up (never in
+                               // a correct run; dsx_exec_handoff_timeouts reads it) -- a lost hand-off must not pass silently
   unsigned long long* stamp;  // diagnostic s_memtime stamps of workgroup `stamp_block` (or nullptr)
   int stamp_block;
   int ablate;             // -DDSX_DIAG builds only: DSX_ABLATE timing experiments (results are wrong when non-zero)

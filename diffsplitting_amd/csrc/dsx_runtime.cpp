@@ -643,6 +643,7 @@ struct dsx_exec {
   float* table = nullptr;      // [6][cap]
   int table_cap = 0;
   bool temb_from_table = false;
+  unsigned* handoff_timeouts = nullptr;        // device counter: bounded FULL / FREE spins of k_conv_ws that gave up (0 in a correct run)
   unsigned long long* loop_params = nullptr;   // device {seed, noise address}: per-call values the captured step reads
   // per-call host data (step table, seed, noise address) is staged in pinned memory, one slot per call in flight: a
   // slot is reused only after the event recorded behind its copies has completed, so a second dsx_sample_loop on the
@@ -1056,6 +1057,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
              [=](hipStream_t st) { return launch_splitk_reduce(ra, st); });
     } else {
       ConvArgs w = a;
+      w.handoff_timeouts = ex->handoff_timeouts;
       w.xcd_bands = getenv("DSX_XCD_BANDS") ? atoi(getenv("DSX_XCD_BANDS")) : 1;
       w.ws_wg_per_n = ws_wg_per_n(a);
       {   // division-free start-up of k_conv_ws: quotients and fastdiv magics (see ConvArgs::ws_map)
@@ -1255,6 +1257,7 @@ static int build_plan(dsx_exec* ex) {
   const int B = ex->B;
   ex->step_ctr = (int*)ws_alloc(ex, 256);
   ex->loop_params = (unsigned long long*)(ex->sizing ? nullptr : (char*)ex->step_ctr + 64);
+  ex->handoff_timeouts = (unsigned*)(ex->sizing ? nullptr : (char*)ex->step_ctr + 128);   // (zeroed with the block at create)
   ex->time_buf = (float*)ws_alloc(ex, (size_t)B * sizeof(float));
   ex->film = m->F ? (float*)ws_alloc(ex, (size_t)B * m->F * sizeof(float)) : nullptr;
   ex->in_cond = Tensor();
@@ -1397,6 +1400,14 @@ extern "C" void dsx_exec_destroy(dsx_exec* ex) {
   delete ex;
 }
 extern "C" size_t dsx_exec_workspace_bytes(const dsx_exec* ex) { return ex ? ex->ws_bytes : 0; }
+// Bounded spins of the conv kernel's loader -> compute hand-off (three-image tiles) that gave up since the executor was
+// created: 0 in every correct run; anything else means wrong pixels were produced.  Synchronises the device.
+extern "C" int dsx_exec_handoff_timeouts(dsx_exec* ex, unsigned* count) {
+  if (!ex || !count) return fail(DSX_ERR_INVALID, "null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(count, ex->handoff_timeouts, sizeof(unsigned), hipMemcpyDeviceToHost));
+  return DSX_OK;
+}
 extern "C" int dsx_exec_num_launches(const dsx_exec* ex) { return ex ? ex->launches : 0; }
 
 extern "C" int dsx_exec_num_ops(const dsx_exec* ex) { return ex ? (int)ex->ops.size() : 0; }

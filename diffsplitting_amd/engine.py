@@ -216,6 +216,16 @@ class UNetEngine:
     def workspace_bytes(self, B, H, W, cond_channels=0):
         return int(lib.dsx_exec_workspace_bytes(self.executor(B, H, W, cond_channels)))
 
+    def handoff_timeouts(self):
+        """Sum over this network's executors of dsx_exec_handoff_timeouts: bounded spins of the conv kernel's
+        loader -> compute hand-off that gave up.  0 in every correct run (synchronises the device)."""
+        total = 0
+        for ex in self._execs.values():
+            n = C.c_uint(0)
+            check(lib.dsx_exec_handoff_timeouts(ex, C.byref(n)))
+            total += int(n.value)
+        return total
+
     def num_launches(self, B, H, W, cond_channels=0):
         return int(lib.dsx_exec_num_launches(self.executor(B, H, W, cond_channels)))
 

@@ -111,6 +111,10 @@ typedef struct dsx_exec dsx_exec;
 int dsx_exec_create(dsx_model* m, int B, int H, int W, int cond_channels, dsx_exec** out);
 void dsx_exec_destroy(dsx_exec* ex);
 size_t dsx_exec_workspace_bytes(const dsx_exec* ex);
+/* Diagnostics of the conv kernel's in-workgroup hand-off (bounded spins on LDS counters, tiles with three MFMA
+ * images): how many spins gave up since dsx_exec_create.  0 in every correct run -- a non-zero count means pixels of
+ * some launch were wrong and the caller must not use them.  Synchronises the device. */
+int dsx_exec_handoff_timeouts(dsx_exec* ex, unsigned* count);
 /* Host-only (no device needed): runs the planner's sizing pass and its planning pass for this geometry and
  * reports the workspace bytes each of them walked and the launch count.  The two must agree; dsx_exec_create
  * fails if they do not.  Lets CPU tests pin the planner under every tile-preference environment setting. */

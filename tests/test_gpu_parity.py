@@ -83,6 +83,8 @@ def test_unet_forward_persistent_kernel_forced(name, dev, monkeypatch):
     p = psnr(g["y"], y16)
     print(f"\n{name}: persistent kernel forced: fp32 max-abs {maxabs(y, g['y']):.3e} ({n_ws} ws launches), bf16 PSNR {p:.1f} dB")
     assert p > 35.0
+    # the bounded LDS-counter spins of the loader -> compute hand-off must never have given up
+    assert eng.handoff_timeouts() == 0 and eng16.handoff_timeouts() == 0
 
 
 def test_benchmark_batch_matches_single_image_path(dev):
@@ -104,6 +106,7 @@ def test_benchmark_batch_matches_single_image_path(dev):
     print(f"\nB=16 (persistent kernels, {n_ws} ws launches) vs B=1 (k_conv_mfma): PSNR {p:.1f} dB; vs fp32 golden {psnr(g['y'][0], y16[0]):.1f} dB")
     assert p > 50.0
     assert psnr(g["y"][0], y16[0]) > 35.0
+    assert eng.handoff_timeouts() == 0      # 256-pixel tiles hand over through LDS counters with bounded spins
 
 
 def test_hosted_groupnorm_finalize_is_bitwise_neutral(dev, monkeypatch):
