@@ -1370,11 +1370,12 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   // (not in the two-N-block 3 x 3 instantiation: it is at the register limit, and the extra live values cost its main
   // loop 10 %)
   constexpr bool PF_OK = !(NB == 2 && KS == 3);
+  // (folded into one register at once: these waves wait for the first image anyway, and the main loop has no registers to spare)
   unsigned fin_pf_acc = 0u;
-  if constexpr (PF_OK) fin_pf_acc = l2_prefetch(a.pf, blockIdx.x, gridDim.x, tid, 256);
+  if constexpr (PF_OK) fin_pf_acc = l2_prefetch_fold(l2_prefetch(a.pf, blockIdx.x, gridDim.x, tid, 256));
   if constexpr (KS == 1) {
     if (a.fin_on) {
-      fin_pf_acc |= l2_prefetch(a.fin.pf, blockIdx.x, gridDim.x, tid, 256);
+      fin_pf_acc |= l2_prefetch_fold(l2_prefetch(a.fin.pf, blockIdx.x, gridDim.x, tid, 256));
       const int nitems = a.fin.B * a.fin.groups;
       for (int item = (int)blockIdx.x * 4 + wave; item < nitems; item += (int)gridDim.x * 4)
         gn_finalize_item<1>(a.fin, item % a.fin.B, item / a.fin.B, lane, nullptr);
@@ -1458,7 +1459,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const int nb = blockIdx.x % a.nblocks, b = blockIdx.x / a.nblocks;
   const int C = a.C0 + a.C1;
-  const int nphase = C / (8 * KC);
+  // The 2- and 4-phase instantiations are launched for exactly that many phases (512 / 1024 channels in 16-bit storage),
+  // the 8-phase one for every other count: with a run-time count the "phase exists" branches around the early loads made
+  // hipcc's vmcnt bookkeeping assume the fewest loads on any path, so the GroupNorm arithmetic and the conversion waited
+  // for the first 9 weight fragments instead of running under the weight stream.
+  const int nphase = NPH != 8 ? NPH : C / (8 * KC);
   unsigned char* img = lds + wave * (2 * IMGB);
   float* aff = (float*)(lds + 8 * 2 * IMGB) + wave * (8 * 2 * KC);      // [phase][scale KC | shift KC]
 
@@ -1583,17 +1588,21 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
         }
       }
     }
+    // Group sums over <= 64 lanes in fp32 (a channel's sums over the 64 pixels already are fp32 values of the producer's
+    // epilogue; the xor butterfly gives every lane of a group the same bits), the cancellation-prone E[x^2] - mean^2 in
+    // double, the reciprocal square root by v_rsq_f32 (1 ulp): a dozen instructions per phase instead of a double-
+    // precision butterfly, division and square root (~3 k cycles of this latency-bound kernel's prologue with 8 waves/CU).
+    const float inv_n = 1.0f / (64.0f * (float)cpg);     // H * W * channels per group: a power of two, exact
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
       if (p < nphase) {
         const int c0 = (p * 8 + wave) * KC, c = (c0 & ~63) + lane;
-        double s = gs[p], q = gq[p];
+        float s = (float)gs[p], q = (float)gq[p];
         for (int o = 1; o < cpg; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        const double n = 64.0 * cpg;            // H * W elements per channel
-        const double mean = s / n;
-        double var = q / n - mean * mean;
+        const double mean = (double)s * (double)inv_n;
+        double var = (double)q * (double)inv_n - mean * mean;
         if (var < 0) var = 0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+        const float rstd = __builtin_amdgcn_rsqf((float)var + a.gn_eps);
         const float meanf = (float)mean;
         if (c >= c0 && c < c0 + KC) {
           const float sc = rstd * gg[p];
@@ -1605,7 +1614,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
   }
   // the next image-resident conv's weight slices -> this XCD's L2 (its workgroups with the same label need them): issued
   // behind this kernel's own first loads, a whole kernel duration ahead of their use
-  const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.x, gridDim.x, tid, 512);
+  const PfAcc pf_acc = l2_prefetch(a.pf, blockIdx.x, gridDim.x, tid, 512);
   DSX_STAMP(2);
   __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): the zero fill and the aff table are in LDS
   convert_store(0, raw0);
@@ -1648,6 +1657,20 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
     DSX_STAMP(4 + p);
   }
 
+  // thread -> pixel tid >> 3, channels 4 * (tid & 7) .. + 3 of the block.  Its epilogue operands are requested here, in
+  // front of the barrier that waits for the slowest wave's MFMAs (the weight registers are dead): a memory round trip
+  // that used to follow the reduction.
+  const int px = tid >> 3, cg = (tid & 7) * 4;
+  const int n0 = nb * 32 + cg;
+  const size_t opix = (size_t)b * 64 + px;
+  float4 eb = make_float4(0.f, 0.f, 0.f, 0.f), ef = eb;
+  float er[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) eb = *(const float4*)(a.bias + n0);
+  if (a.film) ef = *(const float4*)(a.film + (size_t)b * a.film_bs + n0);
+  if (a.resid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) er[j] = act_load<DT>(a.resid, opix * a.resid_ld + n0 + j);
+  }
   // ---- the 8 partial sums meet in LDS: part[w][mb][r][lane]
   __syncthreads();
   DSX_STAMP(12);
@@ -1662,7 +1685,6 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
   DSX_STAMP(13);
   // thread -> pixel tid >> 3, channels 4 * (tid & 7) .. + 3 of the block.  Accumulator register r of lane
   // (li, lh) of block mb is pixel 32 mb + li, channel 16 lh + r.
-  const int px = tid >> 3, cg = (tid & 7) * 4;
   const int mbo = px >> 5, lo = (px & 31) + 32 * (cg >> 4), r0 = cg & 15;
   float x[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1670,14 +1692,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
     const float4 t = *(const float4*)(part + ((w * 2 + mbo) * 64 + lo) * 20 + r0);
     x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w;
   }
-  const int n0 = nb * 32 + cg;
-  const size_t opix = (size_t)b * 64 + px;
-  if (a.bias) { const float4 t = *(const float4*)(a.bias + n0); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
-  if (a.film) { const float4 t = *(const float4*)(a.film + (size_t)b * a.film_bs + n0); x[0] += t.x; x[1] += t.y; x[2] += t.z; x[3] += t.w; }
-  if (a.resid) {
+  // (same order of additions as before the hoist: bias, FiLM, residual; absent operands are exact zeros)
+  x[0] += eb.x; x[1] += eb.y; x[2] += eb.z; x[3] += eb.w;
+  x[0] += ef.x; x[1] += ef.y; x[2] += ef.z; x[3] += ef.w;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] += act_load<DT>(a.resid, opix * a.resid_ld + n0 + j);
-  }
+  for (int j = 0; j < 4; ++j) x[j] += er[j];
   const int okind = a.out_bf16;
   if (okind == 0) {
     *(float4*)((float*)a.out + opix * a.out_ld + n0) = make_float4(x[0], x[1], x[2], x[3]);
@@ -1748,9 +1767,9 @@ template <typename DT, int KS> static hipError_t launch_img_ks(const ConvArgs* a
     if (e == hipSuccess) e = launch_img_one<DT, KS, 8>(a, lds, st);
     return e;
   }
-  const int nphase = (a->C0 + a->C1) / (8 * Chunk<DT>::KC);   // the unroll depth: the smallest instantiation that holds it
-  return nphase <= 2 ? launch_img_one<DT, KS, 2>(a, lds, st)
-       : nphase <= 4 ? launch_img_one<DT, KS, 4>(a, lds, st) : launch_img_one<DT, KS, 8>(a, lds, st);
+  const int nphase = (a->C0 + a->C1) / (8 * Chunk<DT>::KC);   // 2 / 4: the instantiation unrolled for exactly that count
+  return nphase == 2 ? launch_img_one<DT, KS, 2>(a, lds, st)
+       : nphase == 4 ? launch_img_one<DT, KS, 4>(a, lds, st) : launch_img_one<DT, KS, 8>(a, lds, st);
 }
 template <typename DT> static hipError_t launch_img_dt(int ks, const ConvArgs* a, size_t lds, hipStream_t st) {
   return ks == 3 ? launch_img_ks<DT, 3>(a, lds, st) : launch_img_ks<DT, 1>(a, lds, st);

@@ -31,8 +31,15 @@ struct PrefetchArgs {
 inline unsigned fastdiv_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d) + 1u; }
 #if defined(__HIPCC__)
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
-__device__ __forceinline__ unsigned l2_prefetch(const PrefetchArgs& pf, unsigned lin_block, unsigned nblocks_total, int tid, int nthreads) {
-  unsigned acc = 0u;
+// The loaded words stay in four registers of their own until l2_prefetch_retire: the first line a thread requests of
+// each of its first four slices is a plain assignment, so no s_waitcnt stands between the prefetch and the kernel's own
+// work (an `acc |= load` there made the issuing waves of k_conv_img wait vmcnt(0), i.e. for their whole weight stream,
+// before they converted their slice of the image: they reached the workgroup barrier ~5 k cycles after the others).
+// Further lines (a share longer than the thread count, more than four slices per label: not in the plans built here)
+// are OR-ed in and do wait.
+struct PfAcc { unsigned v[4]; };
+__device__ __forceinline__ PfAcc l2_prefetch(const PrefetchArgs& pf, unsigned lin_block, unsigned nblocks_total, int tid, int nthreads) {
+  PfAcc acc = {{0u, 0u, 0u, 0u}};
   if (pf.base == nullptr || pf.nslices <= 0) return acc;
   const unsigned label = lin_block & 7u, j = lin_block >> 3, n8 = (nblocks_total + 7u) >> 3;
   const unsigned lines = pf.slice_bytes >> 7;            // whole 128-byte lines (slices are multiples of 1 KiB)
@@ -40,14 +47,29 @@ __device__ __forceinline__ unsigned l2_prefetch(const PrefetchArgs& pf, unsigned
   const unsigned l1 = l0 + per < lines ? l0 + per : lines;
   const int s0 = pf.nslices < 8 ? (int)(label % (unsigned)pf.nslices) : (int)label;
   const int sstep = pf.nslices < 8 ? pf.nslices : 8;     // nslices < 8: exactly one slice
-  for (int sl = s0; sl < pf.nslices; sl += sstep) {
+  int sl = s0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (sl < pf.nslices) {
+      const char* b = (const char*)pf.base + (size_t)sl * pf.slice_bytes;
+      unsigned l = l0 + (unsigned)tid;
+      if (l < l1) acc.v[k] = *(const unsigned*)(b + (size_t)l * 128);
+      for (l += (unsigned)nthreads; l < l1; l += (unsigned)nthreads) acc.v[k] |= *(const unsigned*)(b + (size_t)l * 128);
+      sl += sstep;
+    }
+  }
+  for (; sl < pf.nslices; sl += sstep) {
     const char* b = (const char*)pf.base + (size_t)sl * pf.slice_bytes;
-    for (unsigned l = l0 + (unsigned)tid; l < l1; l += (unsigned)nthreads) acc |= *(const unsigned*)(b + (size_t)l * 128);
+    for (unsigned l = l0 + (unsigned)tid; l < l1; l += (unsigned)nthreads) acc.v[3] |= *(const unsigned*)(b + (size_t)l * 128);
   }
   return acc;
 }
+__device__ __forceinline__ unsigned l2_prefetch_fold(const PfAcc& acc) { return acc.v[0] | acc.v[1] | acc.v[2] | acc.v[3]; }   // waits for the loads
 __device__ __forceinline__ void l2_prefetch_retire(const PrefetchArgs& pf, unsigned acc) {
-  if (pf.sink != nullptr) *pf.sink = acc;                 // never taken: keeps the prefetch loads alive
+  if (pf.sink != nullptr) *pf.sink = acc;
+}
+__device__ __forceinline__ void l2_prefetch_retire(const PrefetchArgs& pf, const PfAcc& acc) {
+  if (pf.sink != nullptr) *pf.sink = acc.v[0] | acc.v[1] | acc.v[2] | acc.v[3];   // never taken: keeps the prefetch loads alive
 }
 #endif
 

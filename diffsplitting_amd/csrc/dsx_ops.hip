@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
   // one wave per (image, group)
   const int lane = threadIdx.x;
   // first, so that they fly together with this launch's own loads: the consumer conv's weight slices -> this XCD's L2
-  const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, lane, 64);
+  const PfAcc pf_acc = l2_prefetch(a.pf, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, lane, 64);
   gn_finalize_item<1>(a, blockIdx.x, blockIdx.y, lane, nullptr);
   l2_prefetch_retire(a.pf, pf_acc);
 }
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
 __global__ __launch_bounds__(256) void k_gn_finalize_wide(const GnFinArgs a) {
   __shared__ double red[8];
   const int tid = threadIdx.x;
-  const unsigned pf_acc = l2_prefetch(a.pf, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, 256);
+  const PfAcc pf_acc = l2_prefetch(a.pf, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tid, 256);
   gn_finalize_item<4>(a, blockIdx.x, blockIdx.y, tid, red);
   l2_prefetch_retire(a.pf, pf_acc);
 }
