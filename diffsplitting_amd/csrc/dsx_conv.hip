@@ -89,6 +89,34 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __forceinline__ float swish_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
+// The same arithmetic on element pairs, written with two-element vectors so that hipcc selects the packed fp32
+// instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: one issue slot for two elements; the scalar spelling gets
+// one v_mul / v_add per element).  Results are bit-identical to swish_f / x * s + h: the same operations in the same
+// order (v_exp_f32 is 2^x: __expf(-v) is the product with -log2(e), then v_exp_f32).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+template <int N> __device__ __forceinline__ void swish_vec(float (&v)[N]) {
+  static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    f32x2_t x = {v[j], v[j + 1]};
+    const f32x2_t k = {-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2_t t = x * k;
+    f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + 1.0f;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    x = x * r;
+    v[j] = x.x; v[j + 1] = x.y;
+  }
+}
+template <int N> __device__ __forceinline__ void affine_vec(float (&v)[N], const float (&sc)[N], const float (&sh)[N]) {
+  static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    const f32x2_t x = {v[j], v[j + 1]}, s = {sc[j], sc[j + 1]}, h = {sh[j], sh[j + 1]};
+    const f32x2_t y = x * s + h;               // contracted to v_pk_fma_f32 (as the scalar form is to v_fma_f32)
+    v[j] = y.x; v[j + 1] = y.y;
+  }
+}
 
 // 16 per-lane registers -> one total per lane: lane i of a DPP row ends up with the row's sum of register
 // r = 8*bit0(i) + 4*bit1(i) + 2*bit2(i) + bit3(i).  Each butterfly stage halves the register count (the
@@ -126,17 +154,19 @@ __device__ __forceinline__ int row16_fold_reg(int lane) {
   return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
 }
 
+// (vector conversions: one v_cvt_pk_* per pair; converted one by one each element costs a convert, and the pair a shift and an or)
+typedef __attribute__((ext_vector_type(2))) float f32x2_cvt;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cvt;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_cvt;
 __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
-  const _Float16 l = (_Float16)lo, h = (_Float16)hi;  // RNE (v_cvt_f16_f32)
-  return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+  const f32x2_cvt v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_cvt));   // RNE
 }
 __device__ __forceinline__ float f16_lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
 __device__ __forceinline__ float f16_hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  __bf16 l = (__bf16)lo, h = (__bf16)hi;  // RNE (v_cvt_pk_bf16_f32)
-  unsigned short ls = __builtin_bit_cast(unsigned short, l);
-  unsigned short hs = __builtin_bit_cast(unsigned short, h);
-  return (unsigned)ls | ((unsigned)hs << 16);
+  const f32x2_cvt v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_cvt));  // RNE (v_cvt_pk_bf16_f32)
 }
 
 // diagnostic stamps (DSX_STAMP_OP): wave 0 of one chosen workgroup records s_memtime at phase
@@ -653,13 +683,9 @@ __global__ __launch_bounds__(256, ((KS == 3 && CPG == 2) ? 2   // two-chunk 3 x 
         if (soff[it] >= 0 && c < C && !DSX_ABLATED(1)) {   // padding pixels stay exactly 0 (padded AFTER the activation)
           if (has_gn) {
             if (multi_img) load_affine(simg[it]);
-#pragma unroll
-            for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
+            affine_vec(v, sc, sh);
           }
-          if (a.swish) {
-#pragma unroll
-            for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
-          }
+          if (a.swish) swish_vec(v);
           if ((a.stage_mode == 2)) {  // channels past C inside the last unit must stay 0
 #pragma unroll
             for (int j = 1; j < CPU; ++j) if (c + j >= C) v[j] = 0.f;
@@ -1072,12 +1098,17 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
 #pragma unroll
       for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rv[it]));
       DSX_STAMP_T(121, tid == 256 && DSX_STAMP_CVT_COND);
+      // lanes without a GroupNorm in front (gnF is per lane: channels past C) multiply by 1 and add 0 -- exact -- so the
+      // unit loop has one unconditional packed fma per pair instead of a select per element
       float sc[CPU], sh[CPU];
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
-        sc[4 * q] = av[q].x; sc[4 * q + 1] = av[q].y; sc[4 * q + 2] = av[q].z; sc[4 * q + 3] = av[q].w;
-        sh[4 * q] = av[NA + q].x; sh[4 * q + 1] = av[NA + q].y; sh[4 * q + 2] = av[NA + q].z; sh[4 * q + 3] = av[NA + q].w;
+        sc[4 * q] = gnF ? av[q].x : 1.0f; sc[4 * q + 1] = gnF ? av[q].y : 1.0f;
+        sc[4 * q + 2] = gnF ? av[q].z : 1.0f; sc[4 * q + 3] = gnF ? av[q].w : 1.0f;
+        sh[4 * q] = gnF ? av[NA + q].x : 0.0f; sh[4 * q + 1] = gnF ? av[NA + q].y : 0.0f;
+        sh[4 * q + 2] = gnF ? av[NA + q].z : 0.0f; sh[4 * q + 3] = gnF ? av[NA + q].w : 0.0f;
       }
+      const bool any_gn = a.gn_scale != nullptr;   // uniform
       // one uniform branch around the whole unit loop (a branch per unit keeps the units' arithmetic from interleaving):
       // residual / attention-output 1 x 1 convs and the upsampling convs have no GroupNorm / Swish in front and copy
       // (1 x 1 only: in the 3 x 3 instantiations the extra branch cost the GroupNorm layers 3-4 %, more than the four
@@ -1102,14 +1133,8 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
             // the arithmetic runs in every lane; padding pixels (and channels past C) are forced to exactly 0
             // afterwards with one mask per packed register (padded AFTER the activation, as the reference does)
 #ifndef DSX_ABL_CVT   // -DDSX_ABL_CVT: timing experiment, loaders skip the GroupNorm / Swish arithmetic (results wrong)
-            if (gnF) {
-#pragma unroll
-              for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
-            }
-            if (a.swish) {
-#pragma unroll
-              for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
-            }
+            if (any_gn) affine_vec(v, sc, sh);
+            if (a.swish) swish_vec(v);
 #endif
             if (it == NIT - 1) { asm volatile("" :: "v"(v[0]), "v"(v[CPU - 1])); DSX_STAMP_T(122, tid == 256 && DSX_STAMP_CVT_COND); }
             uint4 w = Unit<DT>::pack(v);
@@ -1506,14 +1531,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_img(const ConvArgs a) {
       const int px = (lane + 64 * i) >> 2;
       float v[CPU];
       Unit<DT>::unpack(raw[i], v);
-      if (a.has_gn) {
-#pragma unroll
-        for (int j = 0; j < CPU; ++j) v[j] = v[j] * sc[j] + sh[j];
-      }
-      if (a.swish) {
-#pragma unroll
-        for (int j = 0; j < CPU; ++j) v[j] = swish_f(v[j]);
-      }
+      if (a.has_gn) affine_vec(v, sc, sh);
+      if (a.swish) swish_vec(v);
       *(uint4*)(buf + ((px >> 3) + PAD) * RB + ((px & 7) + PAD) * PIXB + u * 16) = Unit<DT>::pack(v);
     }
   };
