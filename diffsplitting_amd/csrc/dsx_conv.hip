@@ -2143,10 +2143,13 @@ static constexpr bool ws_tile_ok(int tile) {
   return tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x64 || tile == TILE_64x64 || tile == TILE_256x64;
 }
 int conv_ws_tile_wm(int tile) { return ws_tile(tile).WM; }
-static constexpr int ws_depth(int tile, int ks) {   // P: groups of raw activations in flight beyond the current one
+static constexpr int ws_depth(int tile, int ks, int cpg) {   // P: groups of raw activations in flight beyond the current one
   const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
+  if (ks == 3 && cpg == 2) return bm == 64 ? 3 : 2;   // two-chunk groups are twice as long (and twice the ring bytes)
   return DSX_WS_DEPTH_EXPR;
 }
+// chunks per group of k_conv_ws: the family default, or two for a 3 x 3 conv that asks for it (ConvArgs::ws_cpg)
+static constexpr int ws_cpg_of(int ks, int ws_cpg) { return (ks == 3 && ws_cpg == 2) ? 2 : conv_cpg(ks); }
 static constexpr int kWsLoaderWaves = 4;
 // patch pixels the WS loaders are sized for: one image per tile, square-ish tiles (16x8 / 8x16 -> 18x10,
 // 8x8 -> 10x10, 16x4 -> 18x6); other shapes fall back to k_conv_mfma
@@ -2154,26 +2157,33 @@ static constexpr int ws_max_px(int tile, int ks) {
   const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
   return ks == 1 ? bm : (bm == 256 ? 324 : (bm == 128 ? 180 : 108));
 }
-static constexpr int ws_nit(int dtype, int tile, int ks) {   // staging units per loader thread per group
-  const int upg = 4 * conv_cpg(ks);
-  (void)dtype;
+static constexpr int ws_nit(int tile, int ks, int cpg) {   // staging units per loader thread per group
+  const int upg = 4 * cpg;
   return (ws_max_px(tile, ks) * upg + kWsLoaderWaves * 64 - 1) / (kWsLoaderWaves * 64);
 }
 size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   if (!ws_tile_ok(tile) || !(ks == 1 || ks == 3)) return 0;
   if (tile == TILE_256x64 && ks != 3) return 0;
   if (ws_tile(tile).NB == 2 && dtype == 0) return 0;
-  if (conv_lds_bytes(dtype, tile, ks, 1, a) == 0) return 0;
+  const int cpg = ws_cpg_of(ks, a.ws_cpg);
+  if (ks == 3 && cpg == 2) {
+    // two-chunk 3 x 3 groups: instantiated for the 64-pixel tile (the 16 x 16 maps, where the loaders' per-item costs
+    // bound the item); 144-byte pixels, the row pitch of the other two-chunk kernel
+    const int KC = dtype != 0 ? 32 : 16;
+    if (!(tile == TILE_64x128 || tile == TILE_128x128) || a.cpg == 2 || (a.kchunks & 1) || a.C0 % (2 * KC) || a.C1 % (2 * KC)) return 0;
+    if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != conv_tile_info(tile).BM) return 0;
+    if (a.lds_row != conv_lds_row_g2(a.tw_log2)) return 0;
+  } else if (conv_lds_bytes(dtype, tile, ks, 1, a) == 0) return 0;
   if (patch_pixels(ks, 1, a) > ws_max_px(tile, ks)) return 0;
   if (a.up && (a.tw_log2 == 0 || a.th_log2 == 0)) return 0;   // the loaders assume an even tile origin when upsampling
   const int ph = ((1 << a.th_log2) - 1) + ks;
   const size_t bufb = (size_t)(ph << a.tb_log2) * a.lds_row;
-  const size_t rawb = (size_t)ws_nit(dtype, tile, ks) * (kWsLoaderWaves * 64 * 16);
+  const size_t rawb = (size_t)ws_nit(tile, ks, cpg) * (kWsLoaderWaves * 64 * 16);
   const size_t affb = a.has_gn ? (((size_t)2 * (a.C0 + a.C1) * 4 + 15) & ~(size_t)15) : 0;  // never keyed on a pointer
   const WsTileCfg wt = ws_tile(tile);
   const size_t nbuf = (size_t)ws_nbuf(32 * wt.MB * wt.WM, ks, wt.NB);
-  const size_t total = nbuf * bufb + 3 * affb + (size_t)(ws_depth(tile, ks) + 1) * rawb + (nbuf >= 3 ? 32 : 0);
-  if (a.tb_log2 != 0 || a.kchunks / conv_cpg(ks) < 2) return 0;   // one image per tile, >= 2 channel groups
+  const size_t total = nbuf * bufb + 3 * affb + (size_t)(ws_depth(tile, ks, cpg) + 1) * rawb + (nbuf >= 3 ? 32 : 0);
+  if (a.tb_log2 != 0 || a.kchunks / cpg < 2) return 0;   // one image per tile, >= 2 channel groups
   // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
   if ((long long)a.B * a.Ho * a.Wo * std::max(a.out_ld, a.resid_ld) >= (1LL << 31)) return 0;   // 32-bit element offsets
   const int al = dtype != 0 ? 7 : 3;   // 16-byte rows in elements of the storage type
@@ -2184,18 +2194,17 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   return total <= 160 * 1024 ? total : 0;
 }
 
-template <typename DT, int TILE, int KS>
+template <typename DT, int TILE, int KS, int CPG = conv_cpg(KS)>
 static hipError_t launch_ws_one(const ConvArgs* ap, size_t lds, hipStream_t st) {
   if constexpr (!ws_tile_ok(TILE) || (ws_tile(TILE).NB == 2 && sizeof(DT) == 4)) {
     return ap ? hipErrorInvalidValue : hipSuccess;   // (the fp32 build has no two-N-block variant: registers)
   } else {
     constexpr WsTileCfg t = ws_tile(TILE);
-    constexpr int CPG = conv_cpg(KS);
     // weight ring, in steps: a full group for one N block per wave, half of it (same bytes, same time) for two
     // (1 x 1 with two N blocks per wave or MB 4: a deeper ring spills, and hipcc's spill path fails on this kernel)
     constexpr int D = KS == 1 ? ((t.NB == 2 || t.MB == 4) ? DSX_RING_1X1_NB2 : DSX_RING_1X1_NB1) : ((t.NB == 2 || t.MB == 4) ? 6 : 18);   // (MB 4: four MFMAs per step, and the registers are needed)
-    constexpr int NIT = ws_nit(Kind<DT>::value, TILE, KS);
-    constexpr int P = ws_depth(TILE, KS);
+    constexpr int NIT = ws_nit(TILE, KS, CPG);
+    constexpr int P = ws_depth(TILE, KS, CPG);
     auto kern = k_conv_ws<DT, t.MB, t.WM, t.WN, t.NB, KS, CPG, D, NIT, P, kWsLoaderWaves>;
     if (!ap)
       return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2209,6 +2218,15 @@ template <typename DT>
 static hipError_t launch_ws_dt(int tile, int ks, const ConvArgs* a, size_t lds, hipStream_t st) {
 #define DSX_WS_CASE(T) \
   case T: return ks == 3 ? launch_ws_one<DT, T, 3>(a, lds, st) : launch_ws_one<DT, T, 1>(a, lds, st);
+  if ((tile == TILE_64x128 || tile == TILE_128x128) && ks == 3) {   // + the two-chunk form of these tiles (ConvArgs::ws_cpg == 2)
+    if (!a) {
+      hipError_t e = launch_ws_one<DT, TILE_64x128, 3, 2>(a, lds, st);
+      if (e == hipSuccess) e = launch_ws_one<DT, TILE_128x128, 3, 2>(a, lds, st);
+      if (e != hipSuccess) return e;
+    } else if (a->ws_cpg == 2) {
+      return tile == TILE_64x128 ? launch_ws_one<DT, TILE_64x128, 3, 2>(a, lds, st) : launch_ws_one<DT, TILE_128x128, 3, 2>(a, lds, st);
+    }
+  }
   switch (tile) {
     DSX_WS_CASE(TILE_128x128)
     DSX_WS_CASE(TILE_64x128)

@@ -196,6 +196,8 @@ struct ConvArgs {
                           // 2 with a 3x3: the two-chunk variant of k_conv_mfma (64 input channels per barrier: a
                           // 64-channel layer is ONE group, no K loop)
   int ws_wg_per_n;        // warp-specialised kernel: persistent workgroups per N tile (0: k_conv_mfma)
+  int ws_cpg;             // k_conv_ws, 3x3: 2 = two 64-byte chunks per (tile, group) item (TILE_64x128 only; lds_row =
+                          // conv_lds_row_g2): the loaders' per-item costs are paid once per 64 input channels
   int xcd_bands;          // k_conv_ws: an XCD's workgroups take a contiguous band of M tiles (else round-robin)
   // k_conv_ws start-up without integer divisions (a dozen of them cost ~2000 cycles before the first DMA could be issued):
   // the host passes the quotients it can compute and multiply-high magics (fastdiv) for the per-workgroup ones.

@@ -999,6 +999,20 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   const bool mfma_ok = !ex->m->want_naive && pick_conv(dtype, ks, stride, a, tile);   // (keyed on a.has_gn, never on pointers)
   const bool use_ws = mfma_ok && a.cpg != 2 && ws_enabled && (ks != 1 || ws_1x1_enabled) && stride == 1 && a.stage_mode == 0 &&
                       a.ksplit == 1 && conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
+  if (use_ws && ks == 3) {
+    // Two 64-byte chunks per (tile, group) item where the geometry allows it: under the 16 x 16 MFMA shape the loaders,
+    // not the MFMAs, bound an item (their VALU stream gets 8 of every 16 issue cycles), and their per-item costs (DMA
+    // issue, wait, fetch, barrier: ~1.3 k of 3.2 k cycles per 32 channels on the 64-pixel tile) are paid once per 64
+    // channels this way.  Measured (A/B in one gpurun call): the 512-channel 16 x 16 layers -8 .. -11 %, a 256 -> 512 layer
+    // with only 4 two-chunk groups +7 % (hence the 12-chunk minimum there); the 128 x 128 tile -2.6 % over its 22 launches.
+    static const int ws_g2 = getenv("DSX_WS_G2") ? atoi(getenv("DSX_WS_G2")) : 1;
+    static const int g2_min64 = getenv("DSX_WS_G2_MIN64") ? atoi(getenv("DSX_WS_G2_MIN64")) : 12;     // chunks: fewer -> one-chunk groups
+    static const int g2_min128 = getenv("DSX_WS_G2_MIN128") ? atoi(getenv("DSX_WS_G2_MIN128")) : 4;
+    ConvArgs t2 = a;
+    t2.ws_cpg = 2; t2.lds_row = conv_lds_row_g2(a.tw_log2);
+    const int min_chunks = conv_tile_info(tile).BM == 64 ? g2_min64 : g2_min128;
+    if (ws_g2 && a.kchunks >= min_chunks && conv_ws_lds_bytes(dtype, tile, ks, t2) != 0) { a.ws_cpg = 2; a.lds_row = t2.lds_row; }
+  }
   // (Tried and rejected in round 3, measured: the GroupNorm finalised by the consuming conv's own compute waves during
   // their start-up wait -- 14 to 22 k_gn_finalize launches fewer, but every such conv started 3-7 us later, the same
   // or more than the launch it replaced cost inside the captured graph: step +0.4 .. +1.1 %.  DESIGN.md section 4.)
@@ -1067,7 +1081,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         w.ws_per = NT >> 3;
         w.ws_adv_x = wpn % a.tiles_x; w.ws_adv_y = (wpn / a.tiles_x) % a.tiles_y; w.ws_adv_b = wpn / per_img;
         const int PW = ((1 << a.tw_log2) - 1) + ks;                       // stride 1
-        const int upg = 4 * conv_chunk_multiple(ks);                      // 16-byte units per pixel and group
+        const int upg = 4 * (a.ws_cpg == 2 ? 2 : conv_chunk_multiple(ks));   // 16-byte units per pixel and group
         const int pstep = 256 / upg;                                      // loader threads / units per pixel
         w.ws_dpy = pstep / PW; w.ws_dpx = pstep - w.ws_dpy * PW;
         w.mg_tiles_x = fastdiv_magic((unsigned)a.tiles_x); w.mg_per_img = fastdiv_magic((unsigned)per_img);
@@ -1115,7 +1129,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
             return launch_conv_ws(dtype, tile, ks, b, st);
           });
         } else {
-          add_op(ex, DSX_OP_CONV_MFMA, d + " ws", flops, bytes,
+          add_op(ex, DSX_OP_CONV_MFMA, d + (a.ws_cpg == 2 ? " ws c2" : " ws"), flops, bytes,
                  [=](hipStream_t st) { ConvArgs b = w; b.pf = *npf; return launch_conv_ws(dtype, tile, ks, b, st); });
         }
       } else {
