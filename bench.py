@@ -119,7 +119,7 @@ def fp32_parity_line(sd, B, steps=20):
     del eng
     return {"dtype": "f32", "batch_per_gpu": B, "steps": steps, "ms_per_step": ms, "sustained_tflops": tf,
             "peak": PEAK_TFLOPS["f32"], "frac": tf / PEAK_TFLOPS["f32"],
-            "note": "whole step (UNet forward + update) of the fp32 parity build, v_mfma_f32_32x32x2_f32; peak = dense fp32 MFMA"}
+            "note": "whole step (UNet forward + update) of the fp32 parity build (v_mfma_f32_16x16x4_f32 in k_conv_ws, 32x32x2 in the other conv kernels); peak = dense fp32 MFMA"}
 
 
 def names_of(k):
