@@ -942,6 +942,10 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
       const int kq = (int)fastdiv((unsigned)k, a.mg_per);
       nt = xcd + 8 * (k - kq * a.ws_per);
       p0 = kq;
+    } else if (a.ws_map == 3) {                  // 1 x 1 convs: XCD x owns the M tiles p = x (mod 8) for EVERY N tile -- their
+      const int j = (int)fastdiv((unsigned)k, a.mg_per);   // weights are small, the input is what the L2s would otherwise
+      nt = k - j * a.ws_per;                     // all fetch; consecutive workgroups of an XCD share the M tile
+      p0 = (j << 3) + xcd;                       // (host: ws_per = n_tiles, wpn a multiple of 8)
     } else {
       nt = (int)fastdiv((unsigned)bid, a.mg_wpn);
       p0 = bid - nt * wpn;

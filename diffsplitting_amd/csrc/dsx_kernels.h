@@ -201,7 +201,8 @@ struct ConvArgs {
   int xcd_bands;          // k_conv_ws: an XCD's workgroups take a contiguous band of M tiles (else round-robin)
   // k_conv_ws start-up without integer divisions (a dozen of them cost ~2000 cycles before the first DMA could be issued):
   // the host passes the quotients it can compute and multiply-high magics (fastdiv) for the per-workgroup ones.
-  int ws_map;             // blockIdx -> (N tile, first M tile): 0 N tiles dealt over XCDs (n_tiles in {1,2,4,8}), 1 n_tiles % 8 == 0, 2 plain
+  int ws_map;             // blockIdx -> (N tile, first M tile): 0 N tiles dealt over XCDs (n_tiles in {1,2,4,8}), 1 n_tiles % 8 == 0, 2 plain,
+                          // 3 M tiles dealt over XCDs, every N tile on each (1 x 1 convs; ws_per = n_tiles)
   int ws_nt_log2;         // ws_map 0: log2(n_tiles)
   int ws_per;             // ws_map 1: n_tiles / 8
   int ws_adv_x, ws_adv_y, ws_adv_b;   // tile walk stride wpn decomposed: wpn % tiles_x, (wpn / tiles_x) % tiles_y, wpn / (tiles_x * tiles_y)

@@ -1074,11 +1074,22 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       w.handoff_timeouts = ex->handoff_timeouts;
       w.xcd_bands = getenv("DSX_XCD_BANDS") ? atoi(getenv("DSX_XCD_BANDS")) : 1;
       w.ws_wg_per_n = ws_wg_per_n(a);
+      // 1 x 1 convs with several N tiles: an XCD takes every N tile of its M tiles (ws_map 3).  With the N tiles dealt over
+      // the XCDs (the 3 x 3 choice: there the weights are the larger operand) every L2 fetched most of the input: 65.7 MB
+      // per launch of the 512 -> 1536 qkv conv against 18.4 MB algorithmic (PMC, profiles/r03_pmc_summary.txt).
+      static const int map3_on = getenv("DSX_WS_MAP3") ? atoi(getenv("DSX_WS_MAP3")) : 1;
+      bool map3 = false;
+      if (map3_on && use_ws && ks == 1 && a.n_tiles >= 2 && a.n_tiles <= 32) {
+        int wpn3 = std::max(8, (256 / a.n_tiles) / 8 * 8);
+        if (wpn3 > a.m_tiles) wpn3 = (a.m_tiles + 7) / 8 * 8;
+        w.ws_wg_per_n = wpn3;
+        map3 = true;
+      }
       {   // division-free start-up of k_conv_ws: quotients and fastdiv magics (see ConvArgs::ws_map)
         const int NT = a.n_tiles, wpn = w.ws_wg_per_n, per_img = a.tiles_x * a.tiles_y;
-        w.ws_map = (NT <= 8 && 8 % NT == 0 && wpn % (8 / NT) == 0) ? 0 : ((NT % 8) == 0 ? 1 : 2);
+        w.ws_map = map3 ? 3 : ((NT <= 8 && 8 % NT == 0 && wpn % (8 / NT) == 0) ? 0 : ((NT % 8) == 0 ? 1 : 2));
         w.ws_nt_log2 = NT <= 8 ? ilog2(NT) : 0;
-        w.ws_per = NT >> 3;
+        w.ws_per = map3 ? NT : (NT >> 3);
         w.ws_adv_x = wpn % a.tiles_x; w.ws_adv_y = (wpn / a.tiles_x) % a.tiles_y; w.ws_adv_b = wpn / per_img;
         const int PW = ((1 << a.tw_log2) - 1) + ks;                       // stride 1
         const int upg = 4 * (a.ws_cpg == 2 ? 2 : conv_chunk_multiple(ks));   // 16-byte units per pixel and group
@@ -1109,7 +1120,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         // (k_conv_ws keys its N tile on blockIdx % 8 in exactly these two cases)
         static const int pf_on = getenv("DSX_PREFETCH") ? atoi(getenv("DSX_PREFETCH")) : 1;
         const int NT = a.n_tiles;
-        const bool keyed = (NT <= 8 && 8 % NT == 0 && w.ws_wg_per_n % (8 / NT) == 0) || (NT % 8) == 0;
+        const bool keyed = !map3 && ((NT <= 8 && 8 % NT == 0 && w.ws_wg_per_n % (8 / NT) == 0) || (NT % 8) == 0);
         const size_t wblock = (size_t)a.kchunks * ks * ks * 2 * 1024;     // bytes of one 32-channel N block's fragments
         const PrefetchArgs mine{a.wpack, (unsigned)(wblock * (ti.BN / 32)), NT, nullptr};
         static const int pf_ws = getenv("DSX_PREFETCH_WS") ? atoi(getenv("DSX_PREFETCH_WS")) : 1;
