@@ -427,9 +427,9 @@ __device__ __forceinline__ void store8(void* out, size_t elem, const float (&x)[
 // the compute waves then waited 3500 cycles for the second group) -0.9 % on the step, those layers -10 %; for every
 // 3 x 3 tile -0.5 % (deep-K layers lose 2 us each to the polling); four buffers no better than three.
 #ifndef DSX_WS_NBUF_EXPR
-#define DSX_WS_NBUF_EXPR(bm, ks, nb) ((bm) == 256 && (ks) == 3 ? 3 : 2)
+#define DSX_WS_NBUF_EXPR(bm, ks, nb, cpg) ((bm) == 256 && (ks) == 3 ? 3 : 2)
 #endif
-static constexpr int ws_nbuf(int bm, int ks, int nb) { return DSX_WS_NBUF_EXPR(bm, ks, nb); }
+static constexpr int ws_nbuf(int bm, int ks, int nb, int cpg) { return DSX_WS_NBUF_EXPR(bm, ks, nb, cpg); }
 // a counter PER WAVE (four words, read with one ds_read_b128): a single shared counter would let three fast waves
 // stand in for a slow one, and the image of the item that one is still reading would be overwritten
 static __device__ __forceinline__ void lds_wait_all_ge(unsigned addr, int target, unsigned* timeouts) {
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256 + 64 * LW, 1) void k_conv_ws(const ConvArgs a) 
   const int RB = a.lds_row;
   const int BUFB = (PH << a.tb_log2) * RB;
   // [image 0 .. NBUF-1][GroupNorm scale/shift of three tiles' images][raw ring][FULL, FREE counters]
-  constexpr int NBUF = ws_nbuf(32 * MB * WM, KS, NB);
+  constexpr int NBUF = ws_nbuf(32 * MB * WM, KS, NB, CPG);
   static_assert(NBUF >= 2 && NBUF <= 4, "two images and a barrier, or three / four and counters");
   const int C = a.C0 + a.C1;
   const int AFFB = a.has_gn ? ((2 * C * 4 + 15) & ~15) : 0;     // bytes of one tile's {scale[C], shift[C]}
@@ -2149,7 +2149,10 @@ static constexpr bool ws_tile_ok(int tile) {
 int conv_ws_tile_wm(int tile) { return ws_tile(tile).WM; }
 static constexpr int ws_depth(int tile, int ks, int cpg) {   // P: groups of raw activations in flight beyond the current one
   const int bm = 32 * kTiles[tile].MB * kTiles[tile].WM;
-  if (ks == 3 && cpg == 2) return bm == 64 ? 3 : 2;   // two-chunk groups are twice as long (and twice the ring bytes)
+#ifndef DSX_WS_DEPTH_C2_64
+#define DSX_WS_DEPTH_C2_64 3
+#endif
+  if (ks == 3 && cpg == 2) return bm == 64 ? DSX_WS_DEPTH_C2_64 : 2;   // two-chunk groups are twice as long (and twice the ring bytes)
   return DSX_WS_DEPTH_EXPR;
 }
 // chunks per group of k_conv_ws: the family default, or two for a 3 x 3 conv that asks for it (ConvArgs::ws_cpg)
@@ -2185,7 +2188,7 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   const size_t rawb = (size_t)ws_nit(tile, ks, cpg) * (kWsLoaderWaves * 64 * 16);
   const size_t affb = a.has_gn ? (((size_t)2 * (a.C0 + a.C1) * 4 + 15) & ~(size_t)15) : 0;  // never keyed on a pointer
   const WsTileCfg wt = ws_tile(tile);
-  const size_t nbuf = (size_t)ws_nbuf(32 * wt.MB * wt.WM, ks, wt.NB);
+  const size_t nbuf = (size_t)ws_nbuf(32 * wt.MB * wt.WM, ks, wt.NB, cpg);
   const size_t total = nbuf * bufb + 3 * affb + (size_t)(ws_depth(tile, ks, cpg) + 1) * rawb + (nbuf >= 3 ? 32 : 0);
   if (a.tb_log2 != 0 || a.kchunks / cpg < 2) return 0;   // one image per tile, >= 2 channel groups
   // whole 32-channel blocks, float4 epilogue, scale/shift staged by 256 threads x float4
