@@ -78,15 +78,21 @@ __device__ __forceinline__ int vt_slot(int row, int slot) { return slot ^ (((row
 
 }  // namespace
 
-// NDB: 128-channel chunks of the (padded) head dimension
-template <int ST, int NDB>
+// NDB: 128-channel chunks of the (padded) head dimension.  CS: output-channel split -- CS workgroups share an (image,
+// query tile): each computes the scores over the whole head dimension (the K stream and the cheap S = K.Q^T work are
+// repeated) but only NDB / CS of the 128-channel chunks of O = P.V, i.e. it stages 1/CS of V.  For the 16 x 16 maps of
+// the SR3 UNet (L = 256: 8 query tiles x 16 images = 128 workgroups on 256 CUs, 16 barrier-separated staged units each)
+// CS = 2 fills the chip and shortens every workgroup to 12 units.
+template <int ST, int NDB, int CS>
 __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs a) {
+  static_assert(NDB % CS == 0, "whole chunks per workgroup");
+  constexpr int NDO = NDB / CS;                 // output chunks of this workgroup
   using T = AttnT<ST>;
   constexpr int ES = T::ES, DC = T::DC, VK = T::VK;
   constexpr bool F32 = ST == 0;
   constexpr int KUNITS = NDB * (128 / DC);      // staged K/Q units per key tile
   constexpr int VPC = BK / VK;                  // staged V units per 128-channel chunk
-  constexpr int VUNITS = NDB * VPC;
+  constexpr int VUNITS = NDO * VPC;
   // LDS rows (bytes): +16 B (16-bit: conflict-free ds_read_b128 of 32-row fragments) / +4 B (fp32: ds_read_b32)
   constexpr int KROW = F32 ? (DC + 1) * 4 : DC * 2 + 16;
   constexpr int PROW = F32 ? (BK + 1) * 4 : BK * 2 + 16;
@@ -107,10 +113,13 @@ __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs
 
   // workgroup -> (image, query tile); query tiles of one image share an XCD (they read the same K / V)
   const int QT = (a.L + BQ - 1) / BQ;
-  const int total = a.B * QT;
+  const int total = a.B * QT * CS;
   int j = blockIdx.x;
   if ((total & 7) == 0) j = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
-  const int b = j / QT, q0 = (j - b * QT) * BQ;
+  const int half = CS == 1 ? 0 : j % CS;        // which NDO chunks of the output (the CS workgroups of a tile are neighbours: same XCD)
+  const int jq = CS == 1 ? j : j / CS;
+  const int b = jq / QT, q0 = (jq - b * QT) * BQ;
+  const int chunk0 = half * NDO;
 
   const size_t row0 = (size_t)b * a.L;                // first token row of the image in the qkv tensor
   const size_t ldb = (size_t)a.ld * ES;               // bytes per token row
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs
       if constexpr (F32) {
         // [VK keys][128 channels] as stored: thread -> (key = tid/32 + 8*it, 16-byte segment tid%32)
         const int s32 = tid & 31, r8 = tid >> 5;
-        const int c0 = chunk * 128 + s32 * 4;
+        const int c0 = (chunk0 + chunk) * 128 + s32 * 4;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
           const int key = key0 + part * VK + r8 + 8 * it;
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs
         }
       } else {
         // key pairs (2i, 2i+1) x 16-byte channel segment: thread -> (segment tid%16, pair tid/16 + 16*it)
-        const int c0 = chunk * 128 + seg * 8;
+        const int c0 = (chunk0 + chunk) * 128 + seg * 8;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int key = key0 + 2 * (rsub + 16 * it);
@@ -212,9 +221,9 @@ __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs
     }
   };
 
-  f32x16 oacc[NDB];
+  f32x16 oacc[NDO];
 #pragma unroll
-  for (int c = 0; c < NDB; ++c)
+  for (int c = 0; c < NDO; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;              // per query (lane & 31), replicated in every wave
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs
           l_run = l_run * alpha + tsum;
           m_run = m_new;
 #pragma unroll
-          for (int c = 0; c < NDB; ++c)
+          for (int c = 0; c < NDO; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[c][r] *= alpha;
         }
@@ -332,10 +341,10 @@ __global__ __launch_bounds__(256, (NDB <= 1 ? 2 : 1)) void k_attn(const AttnArgs
   const float inv_l = 1.0f / l_run;
   char* orow = (char*)a.out + ((size_t)b * a.L + q) * (size_t)a.ldo * ES;
 #pragma unroll
-  for (int c = 0; c < NDB; ++c) {
+  for (int c = 0; c < NDO; ++c) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int ch = c * 128 + wave * 32 + 8 * g + 4 * lh;
+      const int ch = (chunk0 + c) * 128 + wave * 32 + 8 * g + 4 * lh;
       if (ch >= a.C) continue;                        // C is a multiple of 4 (host check): whole groups of 4
       const float x0 = oacc[c][4 * g] * inv_l, x1 = oacc[c][4 * g + 1] * inv_l;
       const float x2 = oacc[c][4 * g + 2] * inv_l, x3 = oacc[c][4 * g + 3] * inv_l;
@@ -361,9 +370,9 @@ template <int ST> constexpr size_t attn_lds_bytes() {
   constexpr int KV = (BK * KROW > (F32 ? T::VK : 128) * VROW) ? BK * KROW : (F32 ? T::VK : 128) * VROW;
   return (size_t)KV + (size_t)BQ * KROW + (size_t)BQ * PROW + 2 * 4 * 32 * sizeof(float);
 }
-template <int ST, int NDB> hipError_t launch_attn_one(const AttnArgs& a, hipStream_t st) {
+template <int ST, int NDB, int CS = 1> hipError_t launch_attn_one(const AttnArgs& a, hipStream_t st) {
   const int QT = (a.L + BQ - 1) / BQ;
-  hipLaunchKernelGGL((k_attn<ST, NDB>), dim3((unsigned)(a.B * QT)), dim3(256), attn_lds_bytes<ST>(), st, a);
+  hipLaunchKernelGGL((k_attn<ST, NDB, CS>), dim3((unsigned)(a.B * QT * CS)), dim3(256), attn_lds_bytes<ST>(), st, a);
   return hipGetLastError();
 }
 template <int ST> hipError_t launch_attn_st(const AttnArgs& a, hipStream_t st) {
@@ -371,7 +380,14 @@ template <int ST> hipError_t launch_attn_st(const AttnArgs& a, hipStream_t st) {
   switch (ndb) {
     case 1: return launch_attn_one<ST, 1>(a, st);
     case 2: return launch_attn_one<ST, 2>(a, st);
-    case 3: case 4: return launch_attn_one<ST, 4>(a, st);
+    case 3: case 4: {
+      // few query tiles (the 16 x 16 maps at batch 16: 128 workgroups): two workgroups per tile, half of the output
+      // channels each (measured: 17.9 -> see DESIGN.md); DSX_ATTN_CS=1 keeps one
+      static const int cs_on = getenv("DSX_ATTN_CS") ? atoi(getenv("DSX_ATTN_CS")) : 2;
+      const int QT = (a.L + BQ - 1) / BQ;
+      if (cs_on == 2 && a.B * QT <= 160) return launch_attn_one<ST, 4, 2>(a, st);
+      return launch_attn_one<ST, 4>(a, st);
+    }
     case 5: case 6: case 7: case 8: return launch_attn_one<ST, 8>(a, st);
     default: return hipErrorInvalidValue;             // head dimension > 1024 (no reference config)
   }
