@@ -2153,10 +2153,25 @@ static constexpr int ws_depth(int tile, int ks, int cpg) {   // P: groups of raw
 #define DSX_WS_DEPTH_C2_64 3
 #endif
   if (ks == 3 && cpg == 2) return bm == 64 ? DSX_WS_DEPTH_C2_64 : 2;   // two-chunk groups are twice as long (and twice the ring bytes)
+  if (ks == 3 && cpg == 4) return 1;
+  if (ks == 1 && cpg == 4) return bm == 64 ? 2 : 1;                     // four-chunk groups of a 1 x 1 conv
   return DSX_WS_DEPTH_EXPR;
 }
 // chunks per group of k_conv_ws: the family default, or two for a 3 x 3 conv that asks for it (ConvArgs::ws_cpg)
-static constexpr int ws_cpg_of(int ks, int ws_cpg) { return (ks == 3 && ws_cpg == 2) ? 2 : conv_cpg(ks); }
+static constexpr int ws_cpg_of(int ks, int ws_cpg) {
+  return (ks == 3 && (ws_cpg == 2 || ws_cpg == 4)) ? ws_cpg : ((ks == 1 && ws_cpg == 4) ? 4 : conv_cpg(ks));
+}
+// LDS row pitch of a 3 x 3 image with `cpg` chunks per pixel (the rule of conv_lds_row for 64 cpg + 16 byte pixels)
+int conv_lds_row_3x3_c(int tw_log2, int cpg) {
+  const int pixb = 64 * cpg + 16;
+  const int pw = ((1 << tw_log2) - 1) + 3;
+  int rb = (pw * pixb + 15) & ~15;
+  if (tw_log2 == 4) rb = (rb + 255) & ~255;
+  else if (tw_log2 == 3) { rb = (rb + 127) & ~127; if (((rb >> 7) & 1) == 0) rb += 128; }
+  return rb;
+}
+// LDS row pitch of a 1 x 1 conv's image with four chunks per pixel (272-byte pixels: no halo, consecutive pixels)
+int conv_lds_row_1x1_c4(int tw_log2) { return (((1 << tw_log2) * (64 * 4 + 16)) + 15) & ~15; }
 static constexpr int kWsLoaderWaves = 4;
 // patch pixels the WS loaders are sized for: one image per tile, square-ish tiles (16x8 / 8x16 -> 18x10,
 // 8x8 -> 10x10, 16x4 -> 18x6); other shapes fall back to k_conv_mfma
@@ -2173,13 +2188,24 @@ size_t conv_ws_lds_bytes(int dtype, int tile, int ks, const ConvArgs& a) {
   if (tile == TILE_256x64 && ks != 3) return 0;
   if (ws_tile(tile).NB == 2 && dtype == 0) return 0;
   const int cpg = ws_cpg_of(ks, a.ws_cpg);
-  if (ks == 3 && cpg == 2) {
+  if (ks == 3 && cpg == 4) {
+    const int KC = dtype != 0 ? 32 : 16;
+    if (tile != TILE_64x128 || a.cpg == 2 || (a.kchunks & 3) || a.C0 % (4 * KC) || a.C1 % (4 * KC)) return 0;
+    if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != conv_tile_info(tile).BM) return 0;
+    if (a.lds_row != conv_lds_row_3x3_c(a.tw_log2, 4)) return 0;
+  } else if (ks == 3 && cpg == 2) {
     // two-chunk 3 x 3 groups: instantiated for the 64-pixel tile (the 16 x 16 maps, where the loaders' per-item costs
     // bound the item); 144-byte pixels, the row pitch of the other two-chunk kernel
     const int KC = dtype != 0 ? 32 : 16;
     if (!(tile == TILE_64x128 || tile == TILE_128x128) || a.cpg == 2 || (a.kchunks & 1) || a.C0 % (2 * KC) || a.C1 % (2 * KC)) return 0;
     if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != conv_tile_info(tile).BM) return 0;
     if (a.lds_row != conv_lds_row_g2(a.tw_log2)) return 0;
+  } else if (ks == 1 && cpg == 4) {
+    // four-chunk 1 x 1 groups (128 input channels per item): the 64- and 128-pixel tiles with 128 output channels
+    const int KC = dtype != 0 ? 32 : 16;
+    if (!(tile == TILE_64x128 || tile == TILE_128x128) || (a.kchunks & 3) || a.C0 % (4 * KC) || a.C1 % (4 * KC)) return 0;
+    if ((1 << (a.tw_log2 + a.th_log2 + a.tb_log2)) != conv_tile_info(tile).BM) return 0;
+    if (a.lds_row != conv_lds_row_1x1_c4(a.tw_log2)) return 0;
   } else if (conv_lds_bytes(dtype, tile, ks, 1, a) == 0) return 0;
   if (patch_pixels(ks, 1, a) > ws_max_px(tile, ks)) return 0;
   if (a.up && (a.tw_log2 == 0 || a.th_log2 == 0)) return 0;   // the loaders assume an even tile origin when upsampling
@@ -2225,13 +2251,25 @@ template <typename DT>
 static hipError_t launch_ws_dt(int tile, int ks, const ConvArgs* a, size_t lds, hipStream_t st) {
 #define DSX_WS_CASE(T) \
   case T: return ks == 3 ? launch_ws_one<DT, T, 3>(a, lds, st) : launch_ws_one<DT, T, 1>(a, lds, st);
+  if ((tile == TILE_64x128 || tile == TILE_128x128) && ks == 1) {   // + the four-chunk 1 x 1 form of these tiles (ConvArgs::ws_cpg == 4)
+    if (!a) {
+      hipError_t e = launch_ws_one<DT, TILE_64x128, 1, 4>(a, lds, st);
+      if (e == hipSuccess) e = launch_ws_one<DT, TILE_128x128, 1, 4>(a, lds, st);
+      if (e != hipSuccess) return e;
+    } else if (a->ws_cpg == 4) {
+      return tile == TILE_64x128 ? launch_ws_one<DT, TILE_64x128, 1, 4>(a, lds, st) : launch_ws_one<DT, TILE_128x128, 1, 4>(a, lds, st);
+    }
+  }
   if ((tile == TILE_64x128 || tile == TILE_128x128) && ks == 3) {   // + the two-chunk form of these tiles (ConvArgs::ws_cpg == 2)
     if (!a) {
       hipError_t e = launch_ws_one<DT, TILE_64x128, 3, 2>(a, lds, st);
       if (e == hipSuccess) e = launch_ws_one<DT, TILE_128x128, 3, 2>(a, lds, st);
+      if (e == hipSuccess) e = launch_ws_one<DT, TILE_64x128, 3, 4>(a, lds, st);
       if (e != hipSuccess) return e;
     } else if (a->ws_cpg == 2) {
       return tile == TILE_64x128 ? launch_ws_one<DT, TILE_64x128, 3, 2>(a, lds, st) : launch_ws_one<DT, TILE_128x128, 3, 2>(a, lds, st);
+    } else if (a->ws_cpg == 4 && tile == TILE_64x128) {
+      return launch_ws_one<DT, TILE_64x128, 3, 4>(a, lds, st);
     }
   }
   switch (tile) {

@@ -196,8 +196,9 @@ struct ConvArgs {
                           // 2 with a 3x3: the two-chunk variant of k_conv_mfma (64 input channels per barrier: a
                           // 64-channel layer is ONE group, no K loop)
   int ws_wg_per_n;        // warp-specialised kernel: persistent workgroups per N tile (0: k_conv_mfma)
-  int ws_cpg;             // k_conv_ws, 3x3: 2 = two 64-byte chunks per (tile, group) item (TILE_64x128 only; lds_row =
-                          // conv_lds_row_g2): the loaders' per-item costs are paid once per 64 input channels
+  int ws_cpg;             // k_conv_ws: chunks per (tile, group) item other than the family default -- 2 for a 3 x 3 conv (lds_row =
+                          // conv_lds_row_g2), 4 for a 1 x 1 conv (conv_lds_row_1x1_c4); 64- and 128-pixel tiles: the loaders'
+                          // per-item costs are paid once per 64 / 128 input channels
   int xcd_bands;          // k_conv_ws: an XCD's workgroups take a contiguous band of M tiles (else round-robin)
   // k_conv_ws start-up without integer divisions (a dozen of them cost ~2000 cycles before the first DMA could be issued):
   // the host passes the quotients it can compute and multiply-high magics (fastdiv) for the per-workgroup ones.
@@ -243,6 +244,8 @@ int conv_lds_row(int ks, int stride, int tw_log2);
 // two-chunk-per-group 3x3 variant of k_conv_mfma (ConvArgs::cpg == 2): TILE_128x64 (experiment) and the narrow-output
 // tiles TILE_256x32 / TILE_128x32 (convs with <= 32 output channels, e.g. the UNet's final conv)
 int conv_lds_row_g2(int tw_log2);
+int conv_lds_row_3x3_c(int tw_log2, int cpg);   // 3 x 3 conv of k_conv_ws with cpg chunks per item (ConvArgs::ws_cpg == 4)
+int conv_lds_row_1x1_c4(int tw_log2);   // 1 x 1 conv of k_conv_ws with four chunks per item (ConvArgs::ws_cpg == 4)
 size_t conv_g2_lds_bytes(int tile, const ConvArgs& a);
 // LDS bytes needed by a launch; 0 if the geometry is not supported by `tile`
 size_t conv_lds_bytes(int dtype, int tile, int ks, int stride, const ConvArgs& a);

@@ -1012,6 +1012,17 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
     t2.ws_cpg = 2; t2.lds_row = conv_lds_row_g2(a.tw_log2);
     const int min_chunks = conv_tile_info(tile).BM == 64 ? g2_min64 : g2_min128;
     if (ws_g2 && a.kchunks >= min_chunks && conv_ws_lds_bytes(dtype, tile, ks, t2) != 0) { a.ws_cpg = 2; a.lds_row = t2.lds_row; }
+    static const int g4_min64 = getenv("DSX_WS_G4_MIN64") ? atoi(getenv("DSX_WS_G4_MIN64")) : 1000;   // four chunks (64-pixel tile)
+    ConvArgs t4 = a;
+    t4.ws_cpg = 4; t4.lds_row = conv_lds_row_3x3_c(a.tw_log2, 4);
+    if (ws_g2 && a.kchunks >= g4_min64 && conv_ws_lds_bytes(dtype, tile, ks, t4) != 0) { a.ws_cpg = 4; a.lds_row = t4.lds_row; }
+  }
+  if (use_ws && ks == 1) {   // the same for 1 x 1 convs: four chunks (128 input channels) per item
+    static const int ws_c4 = getenv("DSX_WS_C4") ? atoi(getenv("DSX_WS_C4")) : 1;
+    static const int c4_min = getenv("DSX_WS_C4_MIN") ? atoi(getenv("DSX_WS_C4_MIN")) : 8;   // chunks: at least two groups
+    ConvArgs t4 = a;
+    t4.ws_cpg = 4; t4.lds_row = conv_lds_row_1x1_c4(a.tw_log2);
+    if (ws_c4 && a.kchunks >= c4_min && conv_ws_lds_bytes(dtype, tile, ks, t4) != 0) { a.ws_cpg = 4; a.lds_row = t4.lds_row; }
   }
   // (Tried and rejected in round 3, measured: the GroupNorm finalised by the consuming conv's own compute waves during
   // their start-up wait -- 14 to 22 k_gn_finalize launches fewer, but every such conv started 3-7 us later, the same
@@ -1092,7 +1103,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         w.ws_per = map3 ? NT : (NT >> 3);
         w.ws_adv_x = wpn % a.tiles_x; w.ws_adv_y = (wpn / a.tiles_x) % a.tiles_y; w.ws_adv_b = wpn / per_img;
         const int PW = ((1 << a.tw_log2) - 1) + ks;                       // stride 1
-        const int upg = 4 * (a.ws_cpg == 2 ? 2 : conv_chunk_multiple(ks));   // 16-byte units per pixel and group
+        const int upg = 4 * (a.ws_cpg ? a.ws_cpg : conv_chunk_multiple(ks));   // 16-byte units per pixel and group
         const int pstep = 256 / upg;                                      // loader threads / units per pixel
         w.ws_dpy = pstep / PW; w.ws_dpx = pstep - w.ws_dpy * PW;
         w.mg_tiles_x = fastdiv_magic((unsigned)a.tiles_x); w.mg_per_img = fastdiv_magic((unsigned)per_img);
@@ -1133,14 +1144,14 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
         if (host_fin) {
           auto hf = std::make_shared<dsx_exec::HostedFin>();
           ex->fin_host = hf;
-          add_op(ex, DSX_OP_CONV_MFMA, d + " ws +gn", flops, bytes, [=](hipStream_t st) {
+          add_op(ex, DSX_OP_CONV_MFMA, d + (a.ws_cpg == 4 ? " ws c4 +gn" : " ws +gn"), flops, bytes, [=](hipStream_t st) {
             ConvArgs b = w;
             b.pf = *npf;
             if (hf->on) { b.fin_on = 1; b.fin = hf->a; if (hf->pf) b.fin.pf = *hf->pf; }
             return launch_conv_ws(dtype, tile, ks, b, st);
           });
         } else {
-          add_op(ex, DSX_OP_CONV_MFMA, d + (a.ws_cpg == 2 ? " ws c2" : " ws"), flops, bytes,
+          add_op(ex, DSX_OP_CONV_MFMA, d + (a.ws_cpg == 2 ? " ws c2" : (a.ws_cpg == 4 ? " ws c4" : " ws")), flops, bytes,
                  [=](hipStream_t st) { ConvArgs b = w; b.pf = *npf; return launch_conv_ws(dtype, tile, ks, b, st); });
         }
       } else {
