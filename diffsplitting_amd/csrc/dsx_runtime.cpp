@@ -1012,7 +1012,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
     t2.ws_cpg = 2; t2.lds_row = conv_lds_row_g2(a.tw_log2);
     const int min_chunks = conv_tile_info(tile).BM == 64 ? g2_min64 : g2_min128;
     if (ws_g2 && a.kchunks >= min_chunks && conv_ws_lds_bytes(dtype, tile, ks, t2) != 0) { a.ws_cpg = 2; a.lds_row = t2.lds_row; }
-    static const int g4_min64 = getenv("DSX_WS_G4_MIN64") ? atoi(getenv("DSX_WS_G4_MIN64")) : 1000;   // four chunks (64-pixel tile)
+    static const int g4_min64 = getenv("DSX_WS_G4_MIN64") ? atoi(getenv("DSX_WS_G4_MIN64")) : 16;   // four chunks (64-pixel tile)
     ConvArgs t4 = a;
     t4.ws_cpg = 4; t4.lds_row = conv_lds_row_3x3_c(a.tw_log2, 4);
     if (ws_g2 && a.kchunks >= g4_min64 && conv_ws_lds_bytes(dtype, tile, ks, t4) != 0) { a.ws_cpg = 4; a.lds_row = t4.lds_row; }
