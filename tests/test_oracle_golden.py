@@ -1,6 +1,8 @@
 """The oracle (oracle/) against fixtures generated from the reference's own
 classes (oracle/gen_golden.py) and against the reference's known-answer test
 for the tiling path.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -209,3 +211,21 @@ def test_fullsize_c5_joint_and_time_predictor():
     x = cases.make_fullsize_input("c5_tp_x", (2, 1, 512, 512))
     t = time_predictor_forward(sd, case["cfg"], x)
     np.testing.assert_allclose(t.numpy(), g["t"], rtol=1e-5, atol=1e-6)
+
+
+def test_cached_oracle_run_is_the_oracle():
+    """tests/golden/oracle_run_sr3_2000_tiny.npz (oracle/gen_oracle_cache.py) is the oracle's own 2000-step SR3 loop on
+    the tiny UNet, cached so that the GPU tests need not spend minutes of the GPU box's host on it: recompute it here
+    and compare (1e-5: hosts sum convolutions in different orders; the GPU tests that use it allow 1e-3)."""
+    import numpy as np
+    from tests import gpu_util
+    from oracle import gen_oracle_cache as gc
+    gpu_util.oracle_sr3_loop_tiny.cache_clear()
+    sd, case, sch, cond, draws, full = gpu_util.oracle_sr3_loop_tiny(gc.SCHED, gc.SHAPE, gc.COND_SEED, gc.DRAW_SEED)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_run_sr3_2000_tiny.npz")
+    assert os.path.exists(path), "run python oracle/gen_oracle_cache.py"
+    _, _, _, cond2, draws2, full2 = gpu_util.compute_oracle_sr3_loop_tiny(gc.SCHED, gc.SHAPE, gc.COND_SEED, gc.DRAW_SEED)
+    assert len(draws) == len(draws2) and all(bool((a == b).all()) for a, b in zip(draws[:5] + draws[-5:], draws2[:5] + draws2[-5:]))
+    assert bool((cond == cond2).all())
+    err = float(np.max(np.abs(full.numpy().astype(np.float64) - full2.numpy().astype(np.float64))))
+    assert err <= 1e-5, err
