@@ -1000,26 +1000,27 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
   const bool use_ws = mfma_ok && a.cpg != 2 && ws_enabled && (ks != 1 || ws_1x1_enabled) && stride == 1 && a.stage_mode == 0 &&
                       a.ksplit == 1 && conv_ws_lds_bytes(dtype, tile, ks, a) != 0;
   if (use_ws && ks == 3) {
+    // (these knobs are read at every plan: the tests flip them)
     // Two 64-byte chunks per (tile, group) item where the geometry allows it: under the 16 x 16 MFMA shape the loaders,
     // not the MFMAs, bound an item (their VALU stream gets 8 of every 16 issue cycles), and their per-item costs (DMA
     // issue, wait, fetch, barrier: ~1.3 k of 3.2 k cycles per 32 channels on the 64-pixel tile) are paid once per 64
     // channels this way.  Measured (A/B in one gpurun call): the 512-channel 16 x 16 layers -8 .. -11 %, a 256 -> 512 layer
     // with only 4 two-chunk groups +7 % (hence the 12-chunk minimum there); the 128 x 128 tile -2.6 % over its 22 launches.
-    static const int ws_g2 = getenv("DSX_WS_G2") ? atoi(getenv("DSX_WS_G2")) : 1;
-    static const int g2_min64 = getenv("DSX_WS_G2_MIN64") ? atoi(getenv("DSX_WS_G2_MIN64")) : 12;     // chunks: fewer -> one-chunk groups
-    static const int g2_min128 = getenv("DSX_WS_G2_MIN128") ? atoi(getenv("DSX_WS_G2_MIN128")) : 4;
+    const int ws_g2 = getenv("DSX_WS_G2") ? atoi(getenv("DSX_WS_G2")) : 1;
+    const int g2_min64 = getenv("DSX_WS_G2_MIN64") ? atoi(getenv("DSX_WS_G2_MIN64")) : 12;     // chunks: fewer -> one-chunk groups
+    const int g2_min128 = getenv("DSX_WS_G2_MIN128") ? atoi(getenv("DSX_WS_G2_MIN128")) : 4;
     ConvArgs t2 = a;
     t2.ws_cpg = 2; t2.lds_row = conv_lds_row_g2(a.tw_log2);
     const int min_chunks = conv_tile_info(tile).BM == 64 ? g2_min64 : g2_min128;
     if (ws_g2 && a.kchunks >= min_chunks && conv_ws_lds_bytes(dtype, tile, ks, t2) != 0) { a.ws_cpg = 2; a.lds_row = t2.lds_row; }
-    static const int g4_min64 = getenv("DSX_WS_G4_MIN64") ? atoi(getenv("DSX_WS_G4_MIN64")) : 16;   // four chunks (64-pixel tile)
+    const int g4_min64 = getenv("DSX_WS_G4_MIN64") ? atoi(getenv("DSX_WS_G4_MIN64")) : 16;   // four chunks (64-pixel tile)
     ConvArgs t4 = a;
     t4.ws_cpg = 4; t4.lds_row = conv_lds_row_3x3_c(a.tw_log2, 4);
     if (ws_g2 && a.kchunks >= g4_min64 && conv_ws_lds_bytes(dtype, tile, ks, t4) != 0) { a.ws_cpg = 4; a.lds_row = t4.lds_row; }
   }
   if (use_ws && ks == 1) {   // the same for 1 x 1 convs: four chunks (128 input channels) per item
-    static const int ws_c4 = getenv("DSX_WS_C4") ? atoi(getenv("DSX_WS_C4")) : 1;
-    static const int c4_min = getenv("DSX_WS_C4_MIN") ? atoi(getenv("DSX_WS_C4_MIN")) : 8;   // chunks: at least two groups
+    const int ws_c4 = getenv("DSX_WS_C4") ? atoi(getenv("DSX_WS_C4")) : 1;
+    const int c4_min = getenv("DSX_WS_C4_MIN") ? atoi(getenv("DSX_WS_C4_MIN")) : 8;   // chunks: at least two groups
     ConvArgs t4 = a;
     t4.ws_cpg = 4; t4.lds_row = conv_lds_row_1x1_c4(a.tw_log2);
     if (ws_c4 && a.kchunks >= c4_min && conv_ws_lds_bytes(dtype, tile, ks, t4) != 0) { a.ws_cpg = 4; a.lds_row = t4.lds_row; }
@@ -1088,7 +1089,7 @@ static int plan_conv(dsx_exec* ex, const ConvSpec& s) {
       // 1 x 1 convs with several N tiles: an XCD takes every N tile of its M tiles (ws_map 3).  With the N tiles dealt over
       // the XCDs (the 3 x 3 choice: there the weights are the larger operand) every L2 fetched most of the input: 65.7 MB
       // per launch of the 512 -> 1536 qkv conv against 18.4 MB algorithmic (PMC, profiles/r03_pmc_summary.txt).
-      static const int map3_on = getenv("DSX_WS_MAP3") ? atoi(getenv("DSX_WS_MAP3")) : 1;
+      const int map3_on = getenv("DSX_WS_MAP3") ? atoi(getenv("DSX_WS_MAP3")) : 1;
       bool map3 = false;
       if (map3_on && use_ws && ks == 1 && a.n_tiles >= 2 && a.n_tiles <= 32) {
         int wpn3 = std::max(8, (256 / a.n_tiles) / 8 * 8);

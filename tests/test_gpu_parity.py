@@ -63,25 +63,36 @@ def test_unet_forward_bf16_psnr(name, dev):
     assert p > 35.0
 
 
+# round 3: items of the persistent kernel carry several 64-byte chunks where a layer has enough of them; the second
+# setting lowers the minimum chunk counts so that the small parity grids run the two- and four-chunk forms everywhere
+_WS_FORCED = [{}, {"DSX_WS_G2_MIN64": "2", "DSX_WS_G2_MIN128": "2", "DSX_WS_G4_MIN64": "4", "DSX_WS_C4_MIN": "4"}]
+
+
+@pytest.mark.parametrize("chunks", _WS_FORCED, ids=["default", "many-chunk items"])
 @pytest.mark.parametrize("name", ["sr3_tiny", "ddpm_tiny", "hagen_64", "sr3_128"])
-def test_unet_forward_persistent_kernel_forced(name, dev, monkeypatch):
+def test_unet_forward_persistent_kernel_forced(name, chunks, dev, monkeypatch):
     """The warp-specialised persistent conv kernel (the one the B = 16 benchmark runs on) forced onto the
     small test grids (DSX_WS_MIN_GRID=1): fp32 build within 1e-3 of the golden output, bf16 build by PSNR.
     (ddpm_tiny is 32 x 48: three tiles per row, i.e. the multiply-high divisions of the kernel's start-up with a
     divisor that is not a power of two.)"""
     monkeypatch.setenv("DSX_WS_MIN_GRID", "1")
+    for k, v in chunks.items():
+        monkeypatch.setenv(k, v)
     sd, g = golden_state_dict("unet_" + name)
     case = cases.UNET_CASES[name]
     x, t = cases.make_unet_inputs(name)
     eng = build_engine(case["cfg"], case["flavour"], sd)
-    n_ws = sum("ws" in d.split() for d in eng.op_descriptions(*x.shape[:1], *x.shape[2:]))
+    descs = eng.op_descriptions(*x.shape[:1], *x.shape[2:])
+    n_ws = sum("ws" in d.split() for d in descs)
     assert n_ws > 0, "no launch of this plan uses the persistent kernel"
+    n_multi = sum(("c2" in d.split() or "c4" in d.split()) for d in descs)
     y = eng.forward(x.to(dev), t.to(dev).float() if case["flavour"] == "sr3" else t.to(dev)).cpu().numpy()
     assert maxabs(y, g["y"]) <= FP32_TOL, maxabs(y, g["y"])
     eng16 = build_engine(case["cfg"], case["flavour"], sd, dtype="bf16")
     y16 = eng16.forward(x.to(dev), t.to(dev).float() if case["flavour"] == "sr3" else t.to(dev)).cpu().numpy()
     p = psnr(g["y"], y16)
-    print(f"\n{name}: persistent kernel forced: fp32 max-abs {maxabs(y, g['y']):.3e} ({n_ws} ws launches), bf16 PSNR {p:.1f} dB")
+    print(f"\n{name}: persistent kernel forced: fp32 max-abs {maxabs(y, g['y']):.3e} ({n_ws} ws launches, {n_multi} with "
+          f"several chunks per item in the fp32 plan), bf16 PSNR {p:.1f} dB")
     assert p > 35.0
     # the bounded LDS-counter spins of the loader -> compute hand-off must never have given up
     assert eng.handoff_timeouts() == 0 and eng16.handoff_timeouts() == 0

@@ -41,6 +41,10 @@ ENV_SETS = [
     {"DSX_TILES_NARROW": "3,4,5"}, {"DSX_TILES_WIDE_SPLIT": "1,2,5"}, {"DSX_TILES_NARROW_SPLIT": "4,5"},
     {"DSX_TILES_WS_WIDE": "2"}, {"DSX_TILES_WS_WIDE": "2,1"}, {"DSX_TILES_WS_WIDE_1X1": "2"}, {"DSX_TILES_WS_NARROW": "5"},
     {"DSX_TILES_WS_NARROW": "5,4"}, {"DSX_MIN_GRID": "448", "DSX_TILES_WIDE": "0,2,3,4"}, {"DSX_MIN_GRID": "448", "DSX_WS": "0"},
+    # round 3: chunks per item of the persistent kernel, the 1 x 1 XCD mapping
+    {"DSX_WS_G2": "0"}, {"DSX_WS_C4": "0"}, {"DSX_WS_MAP3": "0"}, {"DSX_WS_G2": "0", "DSX_WS_C4": "0", "DSX_WS_MAP3": "0"},
+    {"DSX_WS_G4_MIN64": "1000"}, {"DSX_WS_G2_MIN64": "2", "DSX_WS_G2_MIN128": "2", "DSX_WS_G4_MIN64": "4", "DSX_WS_C4_MIN": "4"},
+    {"DSX_WS_MIN_GRID": "1", "DSX_WS_G2_MIN64": "2", "DSX_WS_G4_MIN64": "4", "DSX_WS_C4_MIN": "4"},
 ]
 
 _CHILD = r"""
