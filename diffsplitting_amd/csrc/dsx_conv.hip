@@ -22,8 +22,12 @@
 //   MFMA         : bf16  v_mfma_f32_32x32x16_bf16 (1 per 16-B fragment pair)
 //                  fp32  v_mfma_f32_32x32x2_f32   (4 per 16-B fragment pair; exact
 //                        fp32 FMA chain -> the <=1e-3 parity path)
+//                  k_conv_ws (the persistent kernel most launches run on): the 16 x 16 shapes on the SAME packed
+//                  weights -- v_mfma_f32_16x16x32_bf16 / _f16, v_mfma_f32_16x16x4_f32 (see mfma16_step: the chip holds
+//                  a higher clock under them)
 //   epilogue     : weights are the MFMA A operand (rows packed permuted), pixels the B operand: a lane
-//                  holds one pixel x 16 consecutive channels -> 16-byte loads / NHWC stores only.
+//                  holds one pixel x 16 consecutive channels (k_conv_ws: 8 channels of one pixel per 16-pixel block)
+//                  -> 16-byte loads / NHWC stores only.
 #include "dsx_kernels.h"
 #include <algorithm>
 #include <cstdlib>
