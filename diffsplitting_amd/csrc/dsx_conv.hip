@@ -64,7 +64,7 @@
 #define DSX_RING_1X1_NB2 4
 #endif
 #ifndef DSX_LOADER_PRIO
-#define DSX_LOADER_PRIO 1
+#define DSX_LOADER_PRIO 3   // (1 until the 16 x 16 MFMA shape made the loaders the bound of most items; A/B in one call: 3 -0.3 %, 0 +0.5 %)
 #endif
 #ifndef DSX_LOADER_PRIO_EXPR
 #define DSX_LOADER_PRIO_EXPR DSX_LOADER_PRIO   // (may name MB, KS, NB: per-tile experiments)
